@@ -1,0 +1,55 @@
+/*
+ * rt_host.h — C view of the host-side scene library (librt_host.so).
+ *
+ * The C++ classes behind it (raytracer-rs_amd/host/rt_host.hpp) mirror the reference's host API — Scene, World,
+ * HitableList, Triangle/Sphere/Cylinder/Mesh, Material, Light, Camera, SamplerKind, load_obj_file — and flatten a
+ * Scene into the rt_scene_desc consumed by rt_scene_create (rt_api.h).  These entry points expose the scene
+ * catalogue (src/scene.rs:64-699 plus the benchmark scenes assembled from the reference's materials and meshes)
+ * to callers that are not C++ (the ctypes harness, the CLI).
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rth_scene rth_scene;
+
+const char *rth_last_error(void);
+
+/*
+ * Builds a named scene.  `aspect` is the value passed to Camera::new (NX/NY in src/scene.rs:168);
+ * `light_sampler` is the SamplerKind given to the scene constructors (src/bin/main.rs:15-22);
+ * `asset_dir` holds cube.obj, pyramid.obj, utah.obj, miku.obj.
+ * Names: "head" (Scene::cornell_box as it stands at HEAD), "blue_noise_test", "light_test", "mis_test"
+ * (src/scene.rs:356,403,554), and the benchmark scenes "cornell", "whitted", "utah", "miku", "composite".
+ */
+int32_t rth_scene_create(const char *name, float aspect, int32_t light_sampler, const char *asset_dir, rth_scene **out);
+void rth_scene_destroy(rth_scene *s);
+
+/* Borrowed views, valid until rth_scene_destroy. */
+const rt_scene_desc *rth_scene_desc(const rth_scene *s);
+const rt_camera *rth_scene_camera(const rth_scene *s);
+
+/* Camera::new (src/camera.rs:13-27). */
+void rth_camera_new(const float *lookfrom, const float *lookat, const float *vup, float vfov_deg, float aspect, rt_camera *out);
+
+/* Mesh::transform (src/mesh.rs:23-39) applied to n points (3 floats each), in place. */
+void rth_transform_points(float *pts, int32_t n, float scale, const float *disp, float x_deg, float y_deg, float z_deg);
+
+/* load_obj_file (src/obj_loader.rs:16-47): returns the triangle count and a malloc'ed array of 9 floats per face
+ * in *tri_v (free with rth_free), or a negative value on error. */
+int32_t rth_load_obj(const char *path, float **tri_v);
+void rth_free(void *p);
+
+/* Writes the P3 image of src/bin/main.rs:27,51 ("P3\nW H\n255" then one "r g b" line per pixel, top row first)
+ * from the raw integers of rt_resolve. */
+int32_t rth_write_ppm(const char *path, int32_t width, int32_t height, const int32_t *rgb_i32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

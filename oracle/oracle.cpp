@@ -1,0 +1,1482 @@
+// oracle.cpp — CPU restatement of raytracer-rs's per-pixel Monte-Carlo path.
+//
+// THIS IS TEST INFRASTRUCTURE.  It is the checker for the HIP path and the timed CPU baseline; nothing in the
+// product may link, load or call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+//
+// PARITY UNPINNED against the original binary: the reference holds no tests, golden vectors or fixtures, its Rust
+// toolchain is absent here (no cargo/rustc, crates not vendored) and its RNG is OS-seeded (rand::thread_rng), so no
+// output of the reference itself can be reproduced.  What pins this file instead: known-answer vectors derived by
+// hand from the reference source (tests/golden/kat.json) and a statistical comparison with the one committed render
+// whose scene is live at HEAD (output/microfacet.jpg region means, tests/golden/microfacet_regions.json).
+//
+// Structure follows the reference file by file (citations are paths under the reference root):
+//   vector maths      cgmath 0.18.0 (Cargo.lock) — dot = (x*x'+y*y')+z*z', normalize = v * (1/|v|), lerp = a+(b-a)*t
+//   Ray               src/ray.rs:4-12
+//   Camera            src/camera.rs:13-34
+//   Triangle/Sphere/Cylinder   src/geometry.rs:14-193
+//   hit_list          src/hitable.rs:35-62
+//   meshes / BVH      src/mesh.rs:60-309
+//   materials         src/material.rs:36-484
+//   lights            src/light.rs:54-411
+//   samplers          src/sampler.rs:34-296
+//   shaders           src/shader.rs:7-115
+//   pixel loop        src/bin/main.rs:28-52
+//
+// Deliberate, documented departures (the build's definitions, shared with the HIP path):
+//   * rand::thread_rng is replaced by a counter-based generator keyed (seed, pixel, sample, path node, purpose, index);
+//     `gen::<f32>()` keeps its rand 0.8.5 meaning: (u32 >> 8) * 2^-24.
+//   * `choose_mut` (light.rs:310,395) is floor(u32 * len / 2^32).
+//   * rejection loops (material.rs:125-132, sampler.rs:74-79) are capped at 16 tries.
+//   * DiskLight's persistent sampler (light.rs:111,115-127) becomes a counter-indexed stratum (see disk_sample_d).
+//   * cos/sin of 2*pi*r1 in Microfacet::scatter_d (material.rs:344-349) use a fixed polynomial (sincos_2pi) so that
+//     the CPU and the GPU produce the same bits; |error| < 2e-7 against libm (checked in tests).
+//   * mesh acceleration: every mesh flavour returns the brute-force result (closest front-facing face, ties to the
+//     later face).  The reference's BVH drops triangles whose box is flat (mesh.rs:117 `tmax <= tmin`); accel mode 1
+//     here is the reference's tree shape (median split, one face per leaf, both children visited, mesh.rs:225-293)
+//     with padded boxes and the brute-force tie rule, and is tested to agree with brute force.
+//
+// Build: g++ -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  No FMA contraction, IEEE division and
+// sqrt: every geometric quantity is bit-identical with the HIP kernels, which are written with the same
+// operation order.
+
+#include "../include/rt_api.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ vector maths
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 normalize(V3 a) { return a * (1.0f / std::sqrt(dot(a, a))); }
+inline V3 lerp(V3 a, V3 b, float t) { return a + (b - a) * t; }
+// src/lib.rs:26-28
+inline V3 mul_v(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline bool is_black(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+
+const float PI = 3.14159265358979323846f;            // std::f32::consts::PI
+const float ZERO = std::numeric_limits<float>::epsilon(); // src/lib.rs:19
+const V3 BLACK = {0.0f, 0.0f, 0.0f};
+
+// src/lib.rs:31-34
+inline bool vec_eq(V3 a, V3 b, float t_min) {
+    V3 d = a - b;
+    return dot(d, d) < t_min;
+}
+
+// ------------------------------------------------------------------------------------------------ counter RNG
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+inline uint32_t pixel_key(uint32_t seed, uint32_t pixel) { return mix32(mix32(seed ^ 0x9E3779B9U) + pixel); }
+inline uint32_t root_node_key(uint32_t sample) { return mix32(sample + 0x6A09E667U); }
+// branch 0: the ray sampled from the BSDF; branch 1: Microfacet's extra diffuse ray (material.rs:416-438)
+inline uint32_t child_node_key(uint32_t nk, uint32_t branch) { return mix32(nk + 0xBB67AE85U * (branch + 1U)); }
+
+enum Purpose : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_VISIBLE0 = 16 };
+
+struct Stream {
+    uint32_t pk, sk, j;
+    Stream(uint32_t pk_, uint32_t nk, uint32_t purpose) : pk(pk_), sk(mix32(nk + 0x85EBCA6BU * purpose)), j(0) {}
+    uint32_t next_u32() {
+        ++j;
+        return mix32((sk + 0x9E3779B9U * j) ^ pk);
+    }
+    // rand 0.8.5 Standard f32: 24 random bits scaled to [0,1)
+    float next_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+    // stands in for SliceRandom::choose
+    uint32_t next_index(uint32_t n) { return (uint32_t)(((uint64_t)next_u32() * (uint64_t)n) >> 32); }
+};
+
+// cos and sin of 2*pi*r for r in [0,1): exact quadrant reduction, then fixed polynomials on [-pi/4, pi/4].
+inline void sincos_2pi(float r, float *s_out, float *c_out) {
+    int q = (int)(r * 4.0f + 0.5f);
+    float f = r - (float)q * 0.25f;
+    float a = f * 6.28318530717958647692f;
+    float a2 = a * a;
+    float sp = -1.6666654611e-1f + a2 * (8.3321608736e-3f + a2 * -1.9515295891e-4f);
+    float s = a + a * a2 * sp;
+    float cp = 4.166664568298827e-2f + a2 * (-1.388731625493765e-3f + a2 * 2.443315711809948e-5f);
+    float c = 1.0f - 0.5f * a2 + a2 * a2 * cp;
+    switch (q & 3) {
+    case 0: *s_out = s; *c_out = c; break;
+    case 1: *s_out = c; *c_out = -s; break;
+    case 2: *s_out = -s; *c_out = -c; break;
+    default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ray, camera
+struct Ray {
+    V3 o, d;
+    V3 at(float t) const { return o + t * d; } // ray.rs:9-11
+};
+
+// camera.rs:13-27
+void camera_new(V3 lookfrom, V3 lookat, V3 vup, float vfov, float aspect, rt_camera *out) {
+    float theta = vfov * (PI / 180.0f);
+    float half_height = std::tan(theta / 2.0f);
+    float half_width = aspect * half_height;
+    V3 w = normalize(lookfrom - lookat);
+    V3 u = normalize(cross(vup, w));
+    V3 v = cross(w, u);
+    V3 h = 2.0f * half_width * u;
+    V3 vert = 2.0f * half_height * v;
+    out->origin[0] = lookfrom.x; out->origin[1] = lookfrom.y; out->origin[2] = lookfrom.z;
+    out->llc[0] = -half_width; out->llc[1] = -half_height; out->llc[2] = -1.0f;
+    out->horizontal[0] = h.x; out->horizontal[1] = h.y; out->horizontal[2] = h.z;
+    out->vertical[0] = vert.x; out->vertical[1] = vert.y; out->vertical[2] = vert.z;
+}
+
+// camera.rs:29-34
+Ray get_ray(const rt_camera &c, float s, float t) {
+    V3 origin = v3(c.origin[0], c.origin[1], c.origin[2]);
+    V3 llc = v3(c.llc[0], c.llc[1], c.llc[2]);
+    V3 h = v3(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    V3 v = v3(c.vertical[0], c.vertical[1], c.vertical[2]);
+    return Ray{origin, llc + s * h + t * v - origin};
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+struct Tri {
+    V3 v0, v1, v2;
+    int mat;
+    V3 normal() const { return normalize(cross(v1 - v0, v2 - v0)); } // geometry.rs:16-20
+    float area() const {                                             // geometry.rs:23-26
+        V3 c = cross(v1 - v0, v2 - v0);
+        return 0.5f * std::sqrt(dot(c, c));
+    }
+};
+struct Sph { V3 c; float r; int mat; };
+struct Cyl { float cx, cz, ymin, ymax, r; int mat; };
+
+struct Hit {
+    float t;
+    V3 p, n;
+    int mat;
+    int prim;
+};
+
+struct Box {
+    V3 mn, mx;
+};
+
+struct BvhNode { // mesh.rs:188-195; leaf iff left < 0 (face index in `face`)
+    Box box;
+    int left, right;
+    int face;
+};
+
+struct MeshAccel {
+    std::vector<BvhNode> nodes;
+    int root = -1;
+};
+
+struct Object {
+    int kind, first, count, accel;
+    int prim_base;
+    int accel_idx; // into Scene::mesh_accel, -1 = brute force
+};
+
+struct Light {
+    rt_light l;
+    float area;
+    V3 normal;
+};
+
+struct Counters {
+    uint64_t closest = 0, shadow = 0, nodes = 0, tris = 0;
+};
+
+} // namespace
+
+struct orc_scene {
+    std::vector<Tri> tris;
+    std::vector<Sph> sphs;
+    std::vector<Cyl> cyls;
+    std::vector<rt_material> mats;
+    std::vector<Light> lights;
+    std::vector<Tri> ltris;
+    std::vector<Object> objs;
+    std::vector<MeshAccel> mesh_accel;
+    int accel_mode = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &m) {
+    g_err = m;
+    return code;
+}
+
+// geometry.rs:29-63
+bool tri_hit(const Tri &tr, const Ray &r, float t_min, float t_max, bool both_side, Hit *rec) {
+    V3 E1 = tr.v1 - tr.v0;
+    V3 E2 = tr.v2 - tr.v0;
+    V3 P = cross(r.d, E2);
+    float det = dot(P, E1);
+    if (!both_side && det < 0.0f) return false;
+    if (det == 0.0f) return false;
+    float inv_det = 1.0f / det;
+    V3 T = r.o - tr.v0;
+    V3 Q = cross(T, E1);
+    float u = inv_det * dot(P, T);
+    if (u < 0.0f || u > 1.0f) return false;
+    float v = inv_det * dot(Q, r.d);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = inv_det * dot(Q, E2);
+    if (t - 0.0f < t_min || t > t_max) return false;
+    rec->t = t;
+    rec->p = r.at(t);
+    rec->n = normalize(cross(E1, E2));
+    rec->mat = tr.mat;
+    return true;
+}
+
+// geometry.rs:82-117
+bool sph_hit(const Sph &s, const Ray &r, float t_min, float t_max, Hit *rec) {
+    V3 oc = r.o - s.c;
+    float a = dot(r.d, r.d);
+    float b = dot(oc, r.d);
+    float c = dot(oc, oc) - s.r * s.r;
+    float d = b * b - a * c;
+    if (d > t_min) {
+        float temp = (-b - std::sqrt(b * b - a * c)) / a;
+        if (temp < t_max && temp > t_min) {
+            rec->t = temp;
+            rec->p = r.at(temp);
+            rec->n = (rec->p - s.c) / s.r;
+            rec->mat = s.mat;
+            return true;
+        }
+        temp = (-b + std::sqrt(b * b - a * c)) / a;
+        if (temp < t_max && temp > t_min) {
+            rec->t = temp;
+            rec->p = r.at(temp);
+            rec->n = (rec->p - s.c) / s.r;
+            rec->mat = s.mat;
+            return true;
+        }
+    }
+    return false;
+}
+
+// geometry.rs:128-193
+bool cyl_hit(const Cyl &cy, const Ray &r, float t_min, float t_max, Hit *rec) {
+    float t_top = (cy.ymax - r.o.y) / r.d.y;
+    float t_bottom = (cy.ymin - r.o.y) / r.d.y;
+    V3 p_top = r.at(t_top);
+    float dtx = p_top.x - cy.cx, dtz = p_top.z - cy.cz;
+    bool hit_top = t_top > t_min && t_top < t_max && (dtx * dtx + dtz * dtz) < cy.r * cy.r;
+    V3 p_bottom = r.at(t_bottom);
+    float dbx = p_bottom.x - cy.cx, dbz = p_bottom.z - cy.cz;
+    bool hit_bottom = t_bottom > t_min && t_bottom < t_max && (dbx * dbx + dbz * dbz) < cy.r * cy.r;
+
+    float dx = r.d.x, dz = r.d.z;
+    float ox = r.o.x - cy.cx, oz = r.o.z - cy.cz;
+    float a = dx * dx + dz * dz;
+    float b = dx * ox + dz * oz;
+    float c = (ox * ox + oz * oz) - cy.r * cy.r;
+    float d = b * b - a * c;
+    if (d > t_min) {
+        float temp = (-b - std::sqrt(d)) / a;
+        if (temp < t_max && temp > t_min) {
+            V3 p = r.at(temp);
+            if (p.y > cy.ymin && p.y < cy.ymax) {
+                rec->t = temp;
+                rec->p = p;
+                rec->n = v3(p.x - cy.cx, 0.0f, p.z - cy.cz) / cy.r;
+                rec->mat = cy.mat;
+                return true;
+            }
+        }
+        if (hit_top && t_top < t_bottom) {
+            rec->t = t_top;
+            rec->p = p_top;
+            rec->n = v3(0.0f, 1.0f, 0.0f);
+            rec->mat = cy.mat;
+            return true;
+        } else if (hit_bottom) {
+            rec->t = t_bottom;
+            rec->p = p_bottom;
+            rec->n = v3(0.0f, -1.0f, 0.0f);
+            rec->mat = cy.mat;
+            return true;
+        }
+        temp = (-b + std::sqrt(d)) / a;
+        if (temp < t_max && temp > t_min) {
+            V3 p = r.at(temp);
+            if (p.y > cy.ymin && p.y < cy.ymax) {
+                rec->t = temp;
+                rec->p = p;
+                rec->n = v3(p.x - cy.cx, 0.0f, p.z - cy.cz) / cy.r;
+                rec->mat = cy.mat;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// ---- mesh.rs:101-154 boxes.  hit_box keeps the four divisions and min/max order of mesh.rs:109-122 but rejects
+// only tmax < tmin, and the boxes are padded (see box_pad), so that a flat or grazing box is never a false miss.
+// f32::min / f32::max of Rust: a NaN operand is ignored
+inline float fmin_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+inline float fmax_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+bool hit_box(const Box &bx, const Ray &r, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    const float mn[3] = {bx.mn.x, bx.mn.y, bx.mn.z}, mx[3] = {bx.mx.x, bx.mx.y, bx.mx.z};
+    const float o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+    for (int a = 0; a < 3; a++) {
+        float t0 = fmin_((mn[a] - o[a]) / d[a], (mx[a] - o[a]) / d[a]);
+        float t1 = fmax_((mn[a] - o[a]) / d[a], (mx[a] - o[a]) / d[a]);
+        tmin = fmax_(t0, tmin);
+        tmax = fmin_(t1, tmax);
+        if (tmax < tmin) return false;
+    }
+    return true;
+}
+
+Box tri_box(const Tri &t) { // mesh.rs:124-136
+    Box b;
+    b.mn = v3(fmin_(fmin_(t.v0.x, t.v1.x), t.v2.x), fmin_(fmin_(t.v0.y, t.v1.y), t.v2.y), fmin_(fmin_(t.v0.z, t.v1.z), t.v2.z));
+    b.mx = v3(fmax_(fmax_(t.v0.x, t.v1.x), t.v2.x), fmax_(fmax_(t.v0.y, t.v1.y), t.v2.y), fmax_(fmax_(t.v0.z, t.v1.z), t.v2.z));
+    return b;
+}
+Box box_pad(Box b) {
+    float ext = fmax_(fmax_(b.mx.x - b.mn.x, b.mx.y - b.mn.y), b.mx.z - b.mn.z);
+    float mag = fmax_(fmax_(fmax_(std::fabs(b.mn.x), std::fabs(b.mx.x)), fmax_(std::fabs(b.mn.y), std::fabs(b.mx.y))),
+                      fmax_(std::fabs(b.mn.z), std::fabs(b.mx.z)));
+    float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+    b.mn = b.mn - v3(pad, pad, pad);
+    b.mx = b.mx + v3(pad, pad, pad);
+    return b;
+}
+Box surrounding(Box a, Box b) { // mesh.rs:138-153
+    Box r;
+    r.mn = v3(fmin_(a.mn.x, b.mn.x), fmin_(a.mn.y, b.mn.y), fmin_(a.mn.z, b.mn.z));
+    r.mx = v3(fmax_(a.mx.x, b.mx.x), fmax_(a.mx.y, b.mx.y), fmax_(a.mx.z, b.mx.z));
+    return r;
+}
+
+// mesh.rs:225-261 with rand3() (mesh.rs:197-207) replaced by a deterministic generator
+struct BvhBuilder {
+    const std::vector<Tri> &tris;
+    int first;
+    MeshAccel &acc;
+    uint32_t lcg;
+    int rand3() {
+        lcg = lcg * 1664525U + 1013904223U;
+        return (int)((lcg >> 8) % 3U);
+    }
+    int leaf(int face) {
+        BvhNode n;
+        n.box = box_pad(tri_box(tris[first + face]));
+        n.left = n.right = -1;
+        n.face = face;
+        acc.nodes.push_back(n);
+        return (int)acc.nodes.size() - 1;
+    }
+    int build(std::vector<int> &faces) {
+        int axis = rand3();
+        int left, right;
+        auto key = [&](int f) {
+            Box b = tri_box(tris[first + f]);
+            return axis == 0 ? b.mn.x : axis == 1 ? b.mn.y : b.mn.z;
+        };
+        if (faces.size() == 1) {
+            left = leaf(faces[0]);
+            right = leaf(faces[0]);
+        } else if (faces.size() == 2) {
+            if (key(faces[0]) < key(faces[1])) {
+                left = leaf(faces[0]);
+                right = leaf(faces[1]);
+            } else {
+                left = leaf(faces[1]);
+                right = leaf(faces[0]);
+            }
+        } else {
+            std::stable_sort(faces.begin(), faces.end(), [&](int a, int b) { return key(a) < key(b); });
+            size_t mid = faces.size() / 2;
+            std::vector<int> l(faces.begin(), faces.begin() + mid), rr(faces.begin() + mid, faces.end());
+            left = build(l);
+            right = build(rr);
+        }
+        BvhNode n;
+        n.box = surrounding(acc.nodes[left].box, acc.nodes[right].box);
+        n.left = left;
+        n.right = right;
+        n.face = -1;
+        acc.nodes.push_back(n);
+        return (int)acc.nodes.size() - 1;
+    }
+};
+
+// mesh.rs:263-293: both children with the caller's t_max, keep the smaller t.  Equal t keeps the later face
+// (brute-force rule of hit_list + geometry.rs:53) instead of the reference's "right child".
+bool hit_tree(const orc_scene &sc, const Object &ob, const MeshAccel &acc, int node, const Ray &r, float t_min,
+              float t_max, Hit *rec, Counters *cn) {
+    const BvhNode &n = acc.nodes[node];
+    if (n.left < 0) {
+        cn->tris++;
+        if (tri_hit(sc.tris[ob.first + n.face], r, t_min, t_max, false, rec)) {
+            rec->prim = ob.prim_base + n.face;
+            return true;
+        }
+        return false;
+    }
+    cn->nodes++;
+    if (!hit_box(n.box, r, t_min, t_max)) return false;
+    Hit hl, hr;
+    bool bl = hit_tree(sc, ob, acc, n.left, r, t_min, t_max, &hl, cn);
+    bool br = hit_tree(sc, ob, acc, n.right, r, t_min, t_max, &hr, cn);
+    if (bl && br) {
+        if (hl.t < hr.t || (hl.t == hr.t && hl.prim > hr.prim)) *rec = hl; else *rec = hr;
+        return true;
+    }
+    if (bl) { *rec = hl; return true; }
+    if (br) { *rec = hr; return true; }
+    return false;
+}
+
+// hitable.rs:35-62 over the world list; a mesh is the nested hit_list of mesh.rs:85-89
+bool world_hit(const orc_scene &sc, const Ray &r, float t_min, float t_max, Hit *out, Counters *cn) {
+    bool hit_anything = false;
+    float closest = t_max;
+    Hit tmp;
+    for (const Object &ob : sc.objs) {
+        switch (ob.kind) {
+        case RT_OBJ_TRIANGLE:
+            cn->tris++;
+            if (tri_hit(sc.tris[ob.first], r, t_min, closest, false, &tmp)) {
+                hit_anything = true; closest = tmp.t; tmp.prim = ob.prim_base; *out = tmp;
+            }
+            break;
+        case RT_OBJ_SPHERE:
+            if (sph_hit(sc.sphs[ob.first], r, t_min, closest, &tmp)) {
+                hit_anything = true; closest = tmp.t; tmp.prim = ob.prim_base; *out = tmp;
+            }
+            break;
+        case RT_OBJ_CYLINDER:
+            if (cyl_hit(sc.cyls[ob.first], r, t_min, closest, &tmp)) {
+                hit_anything = true; closest = tmp.t; tmp.prim = ob.prim_base; *out = tmp;
+            }
+            break;
+        case RT_OBJ_MESH:
+            if (ob.accel_idx >= 0) {
+                const MeshAccel &acc = sc.mesh_accel[ob.accel_idx];
+                if (acc.root >= 0 && hit_tree(sc, ob, acc, acc.root, r, t_min, closest, &tmp, cn)) {
+                    hit_anything = true; closest = tmp.t; *out = tmp;
+                }
+            } else {
+                for (int f = 0; f < ob.count; f++) {
+                    cn->tris++;
+                    if (tri_hit(sc.tris[ob.first + f], r, t_min, closest, false, &tmp)) {
+                        hit_anything = true; closest = tmp.t; tmp.prim = ob.prim_base + f; *out = tmp;
+                    }
+                }
+            }
+            break;
+        }
+    }
+    return hit_anything;
+}
+
+// ------------------------------------------------------------------------------------------------ samplers
+// sampler.rs:273-277
+inline bool in_disk(float range, float a, float b) {
+    float radius = range / 2.0f;
+    float dx = a - radius, dy = b - radius;
+    return dx * dx + dy * dy < radius * radius;
+}
+// UniformSampler::new (sampler.rs:103-114)
+inline int edge_rate(int ref_rate) { return (int)std::sqrt((double)ref_rate); }
+// the m-th value taken by UniformSampler's i (or j): interval/2 followed by m additions (sampler.rs:111,129-133)
+inline float grid_coord(float interval, int m) {
+    float v = interval / 2.0f;
+    for (int k = 0; k < m; k++) v += interval;
+    return v;
+}
+
+// k-th point of a fresh sampler of `kind` over [0,range)^2 with reference rate `rate`; false if the sampler yields
+// fewer than k+1 points (Uniform/Jittered yield floor(sqrt(rate))^2, sampler.rs:104-105).
+// BlueNoise == white noise: conflict() scans an empty list while the sequence is generated (sampler.rs:200-214,243-250).
+bool sampler_point(int kind, float range, int rate, int k, Stream &st, float *a, float *b) {
+    if (kind == RT_SAMPLER_WHITE || kind == RT_SAMPLER_BLUE) {
+        if (k >= rate) return false;
+        *a = st.next_f32() * range;
+        *b = st.next_f32() * range;
+        return true;
+    }
+    int e = edge_rate(rate);
+    if (k >= e * e) return false;
+    float interval = range / (float)e;
+    float gi = grid_coord(interval, k % e), gj = grid_coord(interval, k / e);
+    if (kind == RT_SAMPLER_UNIFORM) {
+        *a = gi;
+        *b = gj;
+        return true;
+    }
+    float jitter = interval / 2.0f; // sampler.rs:156
+    *a = gi + st.next_f32() * jitter;
+    *b = gj + st.next_f32() * jitter;
+    return true;
+}
+
+// One point on a disk light for next-event estimation (DiskLight::visible_d, light.rs:183-213).  The reference takes
+// the next in-disk point of a sampler that persists across calls; here the stratum is drawn from the node's stream:
+// white/blue: rejection sampling of [0,2r)^2 (sampler.rs:71-84); uniform/jittered: start at a uniformly drawn grid
+// cell and take the first in-disk point from there on, None when the grid is exhausted (sampler.rs:279-292).
+bool disk_sample_d(int kind, float radius, int ns2, Stream &st, float *a, float *b) {
+    float range = radius * 2.0f;
+    if (kind == RT_SAMPLER_WHITE || kind == RT_SAMPLER_BLUE) {
+        for (int tries = 0; tries < 16; tries++) {
+            float pa = st.next_f32() * range, pb = st.next_f32() * range;
+            if (in_disk(range, pa, pb)) { *a = pa; *b = pb; return true; }
+        }
+        return false;
+    }
+    int e = edge_rate(ns2);
+    int n = e * e;
+    if (n <= 0) return false;
+    int k0 = (int)st.next_index((uint32_t)n);
+    for (int k = k0; k < n; k++) {
+        float pa, pb;
+        sampler_point(kind, range, ns2, k, st, &pa, &pb);
+        if (in_disk(range, pa, pb)) { *a = pa; *b = pb; return true; }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ lights
+// mesh.rs:66-82 over a light's faces
+bool light_mesh_hit(const orc_scene &sc, const Light &L, const Ray &r, float t_min, float t_max, float *t_out) {
+    bool any = false;
+    float closest = t_max;
+    Hit tmp;
+    for (int f = 0; f < L.l.tri_count; f++) {
+        if (tri_hit(sc.ltris[L.l.tri_first + f], r, t_min, closest, true, &tmp)) {
+            any = true;
+            closest = tmp.t;
+        }
+    }
+    *t_out = closest;
+    return any;
+}
+
+// Light::hit for each kind: light.rs:101-103, 223-238, 344-346
+bool light_hit(const orc_scene &sc, const Light &L, const Ray &r, const rt_params &pr, float *t_out) {
+    switch (L.l.kind) {
+    case RT_LIGHT_POINT: return false;
+    case RT_LIGHT_DISK: {
+        float hit_t = (L.l.origin[1] - r.o.y) / r.d.y;
+        if (hit_t < pr.t_min) return false;
+        float hx = r.o.x + hit_t * r.d.x;
+        float hz = r.o.z + hit_t * r.d.z;
+        float rx = hx - L.l.origin[0], rz = hz - L.l.origin[2];
+        if (rx * rx + rz * rz <= L.l.radius * L.l.radius) { *t_out = hit_t; return true; }
+        return false;
+    }
+    default: return light_mesh_hit(sc, L, r, pr.t_min, pr.t_max, t_out);
+    }
+}
+
+// light.rs:142-146
+inline float disk_pdf(const Light &L, V3 dir, float sq_dist) {
+    float area = PI * (L.l.radius * L.l.radius);
+    float cosine = std::fabs(dot(dir, v3(0.0f, 1.0f, 0.0f)));
+    return sq_dist / (cosine * area);
+}
+
+// Light::pdf given the light's own hit: light.rs:97-99, 215-221, 334-342
+float light_pdf_with_t(const Light &L, const Ray &r, bool hit, float t) {
+    if (!hit) return ZERO;
+    switch (L.l.kind) {
+    case RT_LIGHT_POINT: return ZERO;
+    case RT_LIGHT_DISK: return disk_pdf(L, r.d, (t * t) * dot(r.d, r.d));
+    default: {
+        float sq_dist = (t * t) * dot(r.d, r.d);
+        float cosine = std::fabs(dot(r.d, L.normal));
+        return sq_dist / (cosine * L.area);
+    }
+    }
+}
+
+// LightList::_hit (light.rs:355-364): the FIRST light in list order that is hit
+int lights_hit(const orc_scene &sc, const Ray &r, const rt_params &pr, float *t_out) {
+    for (size_t i = 0; i < sc.lights.size(); i++) {
+        float t;
+        if (light_hit(sc, sc.lights[i], r, pr, &t)) { *t_out = t; return (int)i; }
+    }
+    return -1;
+}
+// LightList::pdf (light.rs:399-405)
+float lights_pdf(const orc_scene &sc, const Ray &r, const rt_params &pr) {
+    float t;
+    int li = lights_hit(sc, r, pr, &t);
+    if (li < 0) return ZERO;
+    return light_pdf_with_t(sc.lights[li], r, true, t);
+}
+
+struct LSample {
+    Ray ray;
+    V3 radiance;
+    float p;
+};
+
+inline V3 spectrum_of(const Light &L) { return v3(L.l.spectrum[0], L.l.spectrum[1], L.l.spectrum[2]); }
+inline V3 origin_of(const Light &L) { return v3(L.l.origin[0], L.l.origin[1], L.l.origin[2]); }
+
+inline bool occluded(const orc_scene &sc, const Ray &r, const rt_params &pr, Counters *cn) {
+    Hit h;
+    cn->shadow++;
+    return world_hit(sc, r, pr.t_min, 1.0f - pr.t_min, &h, cn);
+}
+
+// PointLight::visible (light.rs:60-81)
+bool point_visible(const orc_scene &sc, const Light &L, V3 hp, V3 n, const rt_params &pr, Counters *cn, V3 *out) {
+    V3 dir = origin_of(L) - hp;
+    Ray r{hp, dir};
+    if (occluded(sc, r, pr, cn)) return false;
+    *out = spectrum_of(L) * dot(normalize(dir), normalize(n)) / dot(dir, dir);
+    return true;
+}
+
+// light.rs:274-288
+V3 sample_in_triangle(const Tri &t, Stream &st) {
+    float e1 = st.next_f32();
+    float e2 = st.next_f32();
+    float se1 = std::sqrt(e1);
+    float bx = 1.0f - se1, by = e2 * se1;
+    return bx * t.v0 + by * t.v1 + (1.0f - bx - by) * t.v2;
+}
+
+// Light::visible_d per kind: light.rs:83-95, 183-213, 303-332
+bool light_visible_d(const orc_scene &sc, const Light &L, V3 hp, V3 n, const rt_params &pr, Stream &st, Counters *cn,
+                     LSample *out) {
+    switch (L.l.kind) {
+    case RT_LIGHT_POINT: {
+        V3 s;
+        if (!point_visible(sc, L, hp, n, pr, cn, &s)) return false;
+        out->ray = Ray{hp, origin_of(L) - hp};
+        out->radiance = s;
+        out->p = ZERO;
+        return true;
+    }
+    case RT_LIGHT_DISK: {
+        float a, b;
+        if (!disk_sample_d(L.l.sampler_kind, L.l.radius, pr.light_samples, st, &a, &b)) return false;
+        V3 origin = origin_of(L) + v3(a - L.l.radius, 0.0f, b - L.l.radius);
+        V3 dir = origin - hp;
+        Ray r{hp, dir};
+        if (occluded(sc, r, pr, cn)) return false;
+        float cs = dot(normalize(dir), normalize(n));
+        out->ray = r;
+        out->radiance = cs > 0.0f ? spectrum_of(L) * cs : BLACK;
+        out->p = disk_pdf(L, dir, dot(dir, dir));
+        return true;
+    }
+    default: {
+        if (L.l.tri_count <= 0) return false; // choose_mut on an empty list -> None
+        const Tri &t = sc.ltris[L.l.tri_first + (int)st.next_index((uint32_t)L.l.tri_count)];
+        V3 origin = sample_in_triangle(t, st);
+        V3 dir = origin - hp;
+        Ray r{hp, dir};
+        if (occluded(sc, r, pr, cn)) return false;
+        float cs = dot(normalize(dir), normalize(n));
+        out->ray = r;
+        out->radiance = cs > 0.0f ? spectrum_of(L) * cs : BLACK;
+        float t_l;
+        bool h = light_mesh_hit(sc, L, r, pr.t_min, pr.t_max, &t_l);
+        out->p = light_pdf_with_t(L, r, h, t_l);
+        return true;
+    }
+    }
+}
+
+// LightList::visible_d (light.rs:387-397): one light picked uniformly
+bool lights_visible_d(const orc_scene &sc, V3 hp, V3 n, const rt_params &pr, uint32_t pk, uint32_t nk, Counters *cn,
+                      LSample *out) {
+    if (sc.lights.empty()) return false;
+    Stream st(pk, nk, P_NEE);
+    const Light &L = sc.lights[st.next_index((uint32_t)sc.lights.size())];
+    return light_visible_d(sc, L, hp, n, pr, st, cn, out);
+}
+
+// DiskLight::visible (light.rs:150-181): drain a fresh sampler; average of spectrum*cos/dist^2 over the in-disk points
+bool disk_visible(const orc_scene &sc, const Light &L, int light_index, V3 hp, V3 n, const rt_params &pr, uint32_t pk,
+                  uint32_t nk, Counters *cn, V3 *out) {
+    Stream st(pk, nk, P_VISIBLE0 + (uint32_t)light_index);
+    V3 radiance = BLACK;
+    int actual = 0;
+    float range = L.l.radius * 2.0f;
+    int kind = L.l.sampler_kind;
+    for (int k = 0; k < pr.light_samples; k++) {
+        float a, b;
+        bool have = false;
+        if (kind == RT_SAMPLER_WHITE || kind == RT_SAMPLER_BLUE) {
+            for (int tries = 0; tries < 16 && !have; tries++) {
+                a = st.next_f32() * range;
+                b = st.next_f32() * range;
+                have = in_disk(range, a, b);
+            }
+        } else {
+            have = sampler_point(kind, range, pr.light_samples, k, st, &a, &b) && in_disk(range, a, b);
+        }
+        if (!have) continue;
+        actual++;
+        V3 origin = origin_of(L) + v3(a - L.l.radius, 0.0f, b - L.l.radius);
+        V3 dir = origin - hp;
+        Ray r{hp, dir};
+        if (!occluded(sc, r, pr, cn)) radiance = radiance + spectrum_of(L) * dot(normalize(dir), normalize(n)) / dot(dir, dir);
+    }
+    radiance = radiance / (float)actual;
+    if (!is_black(radiance)) {
+        *out = radiance * PI * (L.l.radius * L.l.radius);
+        return true;
+    }
+    return false;
+}
+
+// LightList::visible (light.rs:368-385).  PolygonLight::visible is `assert!(false)` (light.rs:292-301): such scenes
+// are rejected before rendering (see check_supported).
+bool lights_visible(const orc_scene &sc, V3 hp, V3 n, const rt_params &pr, uint32_t pk, uint32_t nk, Counters *cn, V3 *out) {
+    V3 res = BLACK;
+    for (size_t i = 0; i < sc.lights.size(); i++) {
+        const Light &L = sc.lights[i];
+        V3 r;
+        bool ok = false;
+        if (L.l.kind == RT_LIGHT_POINT) ok = point_visible(sc, L, hp, n, pr, cn, &r);
+        else if (L.l.kind == RT_LIGHT_DISK) ok = disk_visible(sc, L, (int)i, hp, n, pr, pk, nk, cn, &r);
+        if (ok) res = res + r;
+    }
+    if (!is_black(res)) { *out = res; return true; }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ materials
+inline V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; } // material.rs:36-38
+
+// material.rs:123-136
+V3 unit_vec_on_sphere(Stream &st) {
+    float r1 = 0.0f, r2 = 0.0f, rsq = 0.0f;
+    for (int tries = 0; tries < 16; tries++) {
+        float a = 1.0f - 2.0f * st.next_f32();
+        float b = 1.0f - 2.0f * st.next_f32();
+        float q = a * a + b * b;
+        if (q < 1.0f) { r1 = a; r2 = b; rsq = q; break; }
+    }
+    float rh = 2.0f * std::sqrt(1.0f - rsq);
+    return v3(r1 * rh, r2 * rh, 1.0f - 2.0f * rsq);
+}
+
+// material.rs:171-180
+bool refract(V3 v, V3 n, float ni_over_nt, float t_min, V3 *out) {
+    V3 uv = normalize(v);
+    float dt = dot(uv, n);
+    float d = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    if (d > t_min) {
+        *out = ni_over_nt * (uv - n * dt) - n * std::sqrt(d);
+        return true;
+    }
+    return false;
+}
+
+inline V3 albedo_of(const rt_material &m) { return v3(m.albedo[0], m.albedo[1], m.albedo[2]); }
+inline V3 f0_of(const rt_material &m) { return v3(m.f0[0], m.f0[1], m.f0[2]); }
+
+// Metal::_brdf (material.rs:52-67)
+bool metal_brdf_ok(V3 din, V3 dout, V3 dnor, float t_min) {
+    din = normalize(din);
+    dout = normalize(dout);
+    return std::fabs(dot(din + dout, dnor)) < t_min;
+}
+// Dielectric::_brdf (material.rs:188-217)
+bool dielectric_brdf_ok(const rt_material &m, V3 din, V3 dout, V3 dnor, float t_min) {
+    V3 outward;
+    float ni_over_nt;
+    if (dot(din, dnor) > t_min) { outward = -dnor; ni_over_nt = m.ref_idx; }
+    else { outward = dnor; ni_over_nt = 1.0f / m.ref_idx; }
+    din = normalize(din);
+    dout = normalize(dout);
+    V3 refracted;
+    if (refract(din, outward, ni_over_nt, t_min, &refracted)) return vec_eq(refracted, dout, t_min);
+    return std::fabs(dot(din + dout, dnor)) < t_min;
+}
+
+// material.rs:275-303
+inline float ggx_distribution(V3 n, V3 h, float alpha) {
+    float noh = dot(n, h);
+    float noh2 = noh * noh;
+    float alpha2 = alpha * alpha;
+    float e = noh2 * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (PI * (e * e));
+}
+inline float ggx_schlick(float nov, float k) { return nov / (k + (1.0f - k) * nov); }
+inline float ggx_partial_geometry_term(V3 l, V3 v, V3 n, float alpha) {
+    float nol = std::fabs(dot(n, l));
+    float nov = std::fabs(dot(n, v));
+    float r = std::sqrt(alpha);
+    float k = ((r + 1.0f) * (r + 1.0f)) / 8.0f;
+    return ggx_schlick(nol, k) * ggx_schlick(nov, k);
+}
+inline V3 fresnel_schlick(V3 din, V3 dnor, V3 f0) {
+    float a = 1.0f - std::fabs(dot(dnor, din));
+    return lerp(f0, v3(1.0f, 1.0f, 1.0f), a * a);
+}
+inline V3 half_vec(V3 a, V3 b) { return normalize(a + b); }
+
+// material.rs:314-323
+void get_local_coordinate(V3 v1, V3 *bx, V3 *by, V3 *bz) {
+    v1 = normalize(v1);
+    V3 v2;
+    if (std::fabs(v1.x) > std::fabs(v1.y)) v2 = v3(-v1.z, 0.0f, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+    else v2 = v3(0.0f, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+    V3 v3_ = cross(v1, v2);
+    *bx = v2;
+    *by = v1;
+    *bz = v3_;
+}
+
+// Material::brdf for all kinds: material.rs:89-95, 153-155, 248-254, 361-378
+V3 mat_brdf(const rt_material &m, V3 din, V3 dout, V3 dnor, float t_min) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE: return albedo_of(m) / PI;
+    case RT_MAT_METAL: return metal_brdf_ok(din, dout, dnor, t_min) ? albedo_of(m) : BLACK;
+    case RT_MAT_DIELECTRIC: return dielectric_brdf_ok(m, din, dout, dnor, t_min) ? v3(1.0f, 1.0f, 1.0f) : BLACK;
+    default: {
+        V3 wg = normalize(dnor);
+        V3 wi = normalize(dout);
+        V3 wo = -normalize(din);
+        V3 wm = half_vec(wi, wo);
+        float alpha = m.roughness * m.roughness;
+        if (dot(wi, wg) <= 0.0f || dot(wi, wm) <= 0.0f) return BLACK;
+        V3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
+        V3 f = fresnel_schlick(wi, wg, f0);
+        float d = ggx_distribution(wg, wm, alpha);
+        float g = ggx_partial_geometry_term(wi, wo, wg, alpha);
+        V3 res = (f * d * g) / (4.0f * std::fabs(dot(wg, wi)) * std::fabs(dot(wg, wo)));
+        return mul_v(albedo_of(m), res);
+    }
+    }
+}
+
+// Material::pdf for all kinds: material.rs:97-103, 157-160, 256-262, 380-391
+float mat_pdf(const rt_material &m, V3 din, V3 dout, V3 dnor, float t_min) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE: return 1.0f / PI;
+    case RT_MAT_METAL: return metal_brdf_ok(din, dout, dnor, t_min) ? 1.0f : ZERO;
+    case RT_MAT_DIELECTRIC: return dielectric_brdf_ok(m, din, dout, dnor, t_min) ? 1.0f : ZERO;
+    default: {
+        V3 wg = normalize(dnor);
+        V3 wo = -normalize(din);
+        V3 wi = normalize(dout);
+        V3 wm = half_vec(wi, wo);
+        float a = m.roughness * m.roughness;
+        float a2 = a * a;
+        float cos_theta = std::fabs(dot(wg, wm));
+        float e = (a2 - 1.0f) * (cos_theta * cos_theta) + 1.0f;
+        float d = a2 / (PI * (e * e));
+        return (d * cos_theta) / (4.0f * std::fabs(dot(wo, wm)));
+    }
+    }
+}
+
+// Material::attenuation: material.rs:105-107, 162-164, 264-266 (Microfacet's asserts, :394-397)
+V3 mat_attenuation(const rt_material &m) {
+    if (m.kind == RT_MAT_DIELECTRIC) return v3(1.0f, 1.0f, 1.0f);
+    return albedo_of(m);
+}
+
+// Material::scatter (Whitted): material.rs:71-83, 139-142, 221-242
+bool mat_scatter(const rt_material &m, const Ray &r_in, const Hit &rec, float t_min, Ray *out) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE: return false;
+    case RT_MAT_METAL: {
+        V3 reflected = reflect(normalize(r_in.d), rec.n);
+        if (dot(reflected, rec.n) > ZERO) { *out = Ray{rec.p, reflected}; return true; }
+        return false;
+    }
+    case RT_MAT_DIELECTRIC: {
+        V3 reflected = reflect(r_in.d, rec.n);
+        V3 outward;
+        float ni_over_nt;
+        if (dot(r_in.d, rec.n) > t_min) { outward = -rec.n; ni_over_nt = m.ref_idx; }
+        else { outward = rec.n; ni_over_nt = 1.0f / m.ref_idx; }
+        V3 refracted;
+        if (refract(r_in.d, outward, ni_over_nt, t_min, &refracted)) *out = Ray{rec.p, refracted};
+        else *out = Ray{rec.p, reflected};
+        return true;
+    }
+    default: return false; // Microfacet::scatter asserts; rejected by check_supported
+    }
+}
+
+// Material::scatter_d: material.rs:85-87, 144-151, 244-246, 334-359
+bool mat_scatter_d(const rt_material &m, const Ray &r_in, const Hit &rec, float t_min, uint32_t pk, uint32_t nk, Ray *out) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE: {
+        Stream st(pk, nk, P_SCATTER);
+        V3 d = unit_vec_on_sphere(st);
+        if (dot(d, rec.n) < 0.0f) d = -d;
+        *out = Ray{rec.p, d};
+        return true;
+    }
+    case RT_MAT_METAL:
+    case RT_MAT_DIELECTRIC: return mat_scatter(m, r_in, rec, t_min, out);
+    default: {
+        Stream st(pk, nk, P_SCATTER);
+        float r0 = st.next_f32();
+        float r1 = st.next_f32();
+        float a = m.roughness * m.roughness;
+        float a2 = a * a;
+        float cos_theta = std::sqrt((1.0f - r0) / ((a2 - 1.0f) * r0 + 1.0f));
+        float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+        float sphi, cphi;
+        sincos_2pi(r1, &sphi, &cphi);
+        float x = sin_theta * cphi;
+        float y = cos_theta;
+        float z = sin_theta * sphi;
+        V3 bx, by, bz;
+        get_local_coordinate(rec.n, &bx, &by, &bz);
+        V3 wm = normalize(x * bx + y * by + z * bz);
+        V3 wo = r_in.d;
+        V3 wi = reflect(wo, wm);
+        *out = Ray{rec.p, wi};
+        return true;
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shaders
+struct Ctx {
+    const orc_scene &sc;
+    const rt_params &pr;
+    uint32_t pk;
+    Counters *cn;
+};
+
+V3 path_trace_shader_mis(const Ctx &cx, const Ray &r, int depth, uint32_t nk);
+
+// the common prologue of shader.rs:28-30, 64-66, 99-101: returns 0 = object is shaded, 1 = light spectrum, 2 = black
+int closer_of(const Ctx &cx, const Ray &r, Hit *rec, V3 *light) {
+    cx.cn->closest++;
+    bool obj = world_hit(cx.sc, r, cx.pr.t_min, cx.pr.t_max, rec, cx.cn);
+    float lt;
+    int li = lights_hit(cx.sc, r, cx.pr, &lt);
+    if (obj) {
+        if (li < 0 || lt > rec->t) return 0;
+        *light = spectrum_of(cx.sc.lights[li]);
+        return 1;
+    }
+    if (li >= 0) { *light = spectrum_of(cx.sc.lights[li]); return 1; }
+    return 2;
+}
+
+// shader.rs:7-13
+V3 normal_shader(const Ctx &cx, const Ray &r) {
+    Hit rec;
+    cx.cn->closest++;
+    if (world_hit(cx.sc, r, cx.pr.t_min, cx.pr.t_max, &rec, cx.cn)) return 0.5f * v3(rec.n.x + 1.0f, rec.n.y + 1.0f, rec.n.z + 1.0f);
+    return v3(0.8f, 0.8f, 0.8f);
+}
+
+// shader.rs:22-55
+V3 whitted_trace_shader(const Ctx &cx, const Ray &r, int depth, uint32_t nk) {
+    if (depth > cx.pr.max_depth) return BLACK;
+    Hit rec;
+    V3 light;
+    int w = closer_of(cx, r, &rec, &light);
+    if (w == 1) return light;
+    if (w == 2) return BLACK;
+    const rt_material &m = cx.sc.mats[rec.mat];
+    Ray scattered;
+    if (mat_scatter(m, r, rec, cx.pr.t_min, &scattered)) {
+        V3 t = whitted_trace_shader(cx, scattered, depth + 1, child_node_key(nk, 0));
+        return mul_v(t, mat_attenuation(m));
+    }
+    V3 direct;
+    if (lights_visible(cx.sc, rec.p, rec.n, cx.pr, cx.pk, nk, cx.cn, &direct)) return mul_v(direct, mat_attenuation(m));
+    return BLACK;
+}
+
+// shader.rs:58-90
+V3 path_trace_shader(const Ctx &cx, const Ray &r, int depth, uint32_t nk) {
+    if (depth > cx.pr.max_depth) return BLACK;
+    Hit rec;
+    V3 light;
+    int w = closer_of(cx, r, &rec, &light);
+    if (w == 1) return light;
+    if (w == 2) return BLACK;
+    const rt_material &m = cx.sc.mats[rec.mat];
+    Ray scattered;
+    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+        V3 t = path_trace_shader(cx, scattered, depth + 1, child_node_key(nk, 0));
+        return mul_v(t, mat_attenuation(m));
+    }
+    return BLACK;
+}
+
+// the NEE term shared by do_material_default and Microfacet::do_material (material.rs:441-447, 473-480)
+V3 direct_term(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, uint32_t nk) {
+    LSample ls;
+    if (lights_visible_d(cx.sc, rec.p, rec.n, cx.pr, cx.pk, nk, cx.cn, &ls)) {
+        float b_pdf = mat_pdf(m, r.d, ls.ray.d, rec.n, cx.pr.t_min);
+        return mul_v(ls.radiance, mat_brdf(m, r.d, ls.ray.d, rec.n, cx.pr.t_min)) / (ls.p + b_pdf);
+    }
+    return BLACK;
+}
+
+// material.rs:454-484
+V3 do_material_default(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, int depth, uint32_t nk) {
+    V3 brdf = BLACK;
+    Ray scattered;
+    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+        V3 li = path_trace_shader_mis(cx, scattered, depth + 1, child_node_key(nk, 0));
+        float l_pdf = lights_pdf(cx.sc, scattered, cx.pr);
+        float b_pdf = mat_pdf(m, r.d, scattered.d, rec.n, cx.pr.t_min);
+        brdf = mul_v(li, mat_brdf(m, r.d, scattered.d, rec.n, cx.pr.t_min)) / (l_pdf + b_pdf);
+    }
+    V3 direct = direct_term(cx, m, r, rec, nk);
+    return brdf + direct;
+}
+
+// material.rs:400-451
+V3 do_material_microfacet(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, int depth, uint32_t nk) {
+    V3 specular = BLACK;
+    Ray scattered;
+    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+        V3 li = path_trace_shader_mis(cx, scattered, depth + 1, child_node_key(nk, 0));
+        float l_pdf = lights_pdf(cx.sc, scattered, cx.pr);
+        float b_pdf = mat_pdf(m, r.d, scattered.d, rec.n, cx.pr.t_min);
+        specular = mul_v(li, mat_brdf(m, r.d, scattered.d, rec.n, cx.pr.t_min)) / (l_pdf + b_pdf);
+    }
+    V3 kd, diffuse;
+    {
+        Stream st(cx.pk, nk, P_DIFFUSE);
+        V3 d = unit_vec_on_sphere(st);
+        if (dot(d, rec.n) < 0.0f) d = -d;
+        Ray sc2{rec.p, d};
+        V3 wi = sc2.d;
+        V3 wg = rec.n;
+        V3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
+        V3 f = fresnel_schlick(wi, wg, f0);
+        kd = (v3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
+        int dd = std::max(depth, cx.pr.max_depth - 6); // material.rs:433: depth.max(34) with max_depth = 40
+        V3 li = path_trace_shader_mis(cx, sc2, dd + 1, child_node_key(nk, 1));
+        float l_pdf = lights_pdf(cx.sc, sc2, cx.pr);
+        float b_pdf = 1.0f / PI;
+        diffuse = mul_v(li, albedo_of(m) / PI) / (l_pdf + b_pdf);
+    }
+    V3 brdf = mul_v(kd, diffuse) + specular;
+    V3 direct = direct_term(cx, m, r, rec, nk);
+    return brdf + direct;
+}
+
+// shader.rs:93-115
+V3 path_trace_shader_mis(const Ctx &cx, const Ray &r, int depth, uint32_t nk) {
+    if (depth > cx.pr.max_depth) return BLACK;
+    Hit rec;
+    V3 light;
+    int w = closer_of(cx, r, &rec, &light);
+    if (w == 1) return light;
+    if (w == 2) return BLACK;
+    const rt_material &m = cx.sc.mats[rec.mat];
+    if (m.kind == RT_MAT_MICROFACET) return do_material_microfacet(cx, m, r, rec, depth, nk);
+    return do_material_default(cx, m, r, rec, depth, nk);
+}
+
+// combinations the reference stops on: material.rs:328-331,394-397 and light.rs:292-301
+int check_supported(const orc_scene &sc, const rt_params &pr) {
+    bool has_mf = false, has_poly = false;
+    for (const Tri &t : sc.tris) has_mf |= sc.mats[t.mat].kind == RT_MAT_MICROFACET;
+    for (const Sph &s : sc.sphs) has_mf |= sc.mats[s.mat].kind == RT_MAT_MICROFACET;
+    for (const Cyl &c : sc.cyls) has_mf |= sc.mats[c.mat].kind == RT_MAT_MICROFACET;
+    for (const Light &L : sc.lights) has_poly |= L.l.kind == RT_LIGHT_POLYGON;
+    if (pr.shader == RT_SHADER_WHITTED && has_mf) return fail(RT_ERR_UNSUPPORTED, "whitted shader: Microfacet::scatter is not supported");
+    if (pr.shader == RT_SHADER_WHITTED && has_poly) return fail(RT_ERR_UNSUPPORTED, "whitted shader: PolygonLight::visible is not supported");
+    if (pr.shader == RT_SHADER_PATH && has_mf) return fail(RT_ERR_UNSUPPORTED, "path shader: Microfacet::attenuation is not supported");
+    return RT_OK;
+}
+
+int check_params(const rt_params &pr) {
+    if (pr.width <= 0 || pr.height <= 0 || pr.spp <= 0) return fail(RT_ERR_INVALID, "width, height and spp must be positive");
+    if (pr.spp_begin < 0 || pr.spp_end < pr.spp_begin || pr.spp_end > pr.spp) return fail(RT_ERR_INVALID, "bad sample range");
+    if (pr.shader < RT_SHADER_NORMAL || pr.shader > RT_SHADER_MIS) return fail(RT_ERR_INVALID, "bad shader");
+    if (pr.pixel_sampler < RT_SAMPLER_WHITE || pr.pixel_sampler > RT_SAMPLER_BLUE) return fail(RT_ERR_INVALID, "unexpected integer"); // sampler.rs:19
+    if (pr.tile_size < 0 || (pr.tile_size > 0 && (pr.shard_count <= 0 || pr.shard_rank < 0 || pr.shard_rank >= pr.shard_count)))
+        return fail(RT_ERR_INVALID, "bad tile sharding");
+    if (pr.max_depth < 0 || pr.max_depth > 62) return fail(RT_ERR_INVALID, "max_depth out of range");
+    if (pr.light_samples < 0) return fail(RT_ERR_INVALID, "light_samples must be >= 0");
+    return RT_OK;
+}
+
+inline bool pixel_selected(const rt_params &pr, int x, int y) {
+    if (pr.tile_size <= 0) return true;
+    int tiles_x = (pr.width + pr.tile_size - 1) / pr.tile_size;
+    int t = (y / pr.tile_size) * tiles_x + (x / pr.tile_size);
+    return t % pr.shard_count == pr.shard_rank;
+}
+
+// one camera sample: main.rs:35-43
+bool camera_sample(const rt_camera &cam, const rt_params &pr, int x, int y, int k, uint32_t pk, uint32_t nk, Ray *out) {
+    Stream st(pk, nk, P_CAMERA);
+    float a, b;
+    if (!sampler_point(pr.pixel_sampler, 1.0f, pr.spp, k, st, &a, &b)) return false;
+    int i = x, j = pr.height - 1 - y;
+    float u = ((float)i + a) / (float)pr.width;
+    float v = ((float)j + b) / (float)pr.height;
+    *out = get_ray(cam, u, v);
+    return true;
+}
+
+int32_t cast_i32(float v) { // Rust `as i32`: saturating, NaN -> 0
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)v;
+}
+
+} // namespace
+
+// ================================================================================================ C entry points
+extern "C" {
+
+const char *orc_last_error(void) { return g_err.c_str(); }
+
+int32_t orc_scene_create(const rt_scene_desc *d, int32_t accel_mode, orc_scene **out) {
+    if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+    orc_scene *s = new orc_scene();
+    s->accel_mode = accel_mode;
+    auto bad = [&](const char *m) { delete s; return fail(RT_ERR_INVALID, m); };
+    if (d->n_tri < 0 || d->n_sph < 0 || d->n_cyl < 0 || d->n_mat < 0 || d->n_light < 0 || d->n_light_tri < 0 || d->n_obj < 0)
+        return bad("negative count");
+    for (int i = 0; i < d->n_mat; i++) s->mats.push_back(d->mats[i]);
+    auto mat_ok = [&](int m) { return m >= 0 && m < d->n_mat; };
+    for (int i = 0; i < d->n_tri; i++) {
+        const float *v = d->tri_v + 9 * i;
+        if (!mat_ok(d->tri_mat[i])) return bad("no material"); // shader.rs:46,81,106 panic!("no material")
+        s->tris.push_back(Tri{v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), v3(v[6], v[7], v[8]), d->tri_mat[i]});
+    }
+    for (int i = 0; i < d->n_sph; i++) {
+        const float *v = d->sph + 4 * i;
+        if (!mat_ok(d->sph_mat[i])) return bad("no material");
+        s->sphs.push_back(Sph{v3(v[0], v[1], v[2]), v[3], d->sph_mat[i]});
+    }
+    for (int i = 0; i < d->n_cyl; i++) {
+        const float *v = d->cyl + 5 * i;
+        if (!mat_ok(d->cyl_mat[i])) return bad("no material");
+        s->cyls.push_back(Cyl{v[0], v[1], v[2], v[3], v[4], d->cyl_mat[i]});
+    }
+    for (int i = 0; i < d->n_light_tri; i++) {
+        const float *v = d->light_tri_v + 9 * i;
+        s->ltris.push_back(Tri{v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), v3(v[6], v[7], v[8]), -1});
+    }
+    for (int i = 0; i < d->n_light; i++) {
+        Light L;
+        L.l = d->lights[i];
+        L.area = 0.0f;
+        L.normal = BLACK;
+        if (L.l.kind == RT_LIGHT_POLYGON) {
+            if (L.l.tri_first < 0 || L.l.tri_count < 1 || L.l.tri_first + L.l.tri_count > d->n_light_tri) return bad("polygon light: bad triangle range");
+            // PolygonLight::new (light.rs:252-269)
+            L.normal = s->ltris[L.l.tri_first].normal();
+            for (int f = 0; f < L.l.tri_count; f++) {
+                const Tri &t = s->ltris[L.l.tri_first + f];
+                L.area += t.area();
+                if (!vec_eq(L.normal, t.normal(), 0.001f)) return bad("the mesh of PolygonLight is not 2D!");
+            }
+        } else if (L.l.kind == RT_LIGHT_DISK) {
+            if (L.l.sampler_kind < RT_SAMPLER_WHITE || L.l.sampler_kind > RT_SAMPLER_BLUE) return bad("unexpected integer");
+        } else if (L.l.kind != RT_LIGHT_POINT) return bad("bad light kind");
+        s->lights.push_back(L);
+    }
+    int prim = 0;
+    int nt = 0, ns = 0, nc = 0;
+    for (int i = 0; i < d->n_obj; i++) {
+        Object ob{d->objects[i].kind, d->objects[i].first, d->objects[i].count, d->objects[i].accel, prim, -1};
+        switch (ob.kind) {
+        case RT_OBJ_TRIANGLE: if (ob.first != nt || ob.count != 1) return bad("objects out of world order"); nt += 1; break;
+        case RT_OBJ_MESH: if (ob.first != nt || ob.count < 0) return bad("objects out of world order"); nt += ob.count; break;
+        case RT_OBJ_SPHERE: if (ob.first != ns || ob.count != 1) return bad("objects out of world order"); ns += 1; break;
+        case RT_OBJ_CYLINDER: if (ob.first != nc || ob.count != 1) return bad("objects out of world order"); nc += 1; break;
+        default: return bad("bad object kind");
+        }
+        prim += ob.count;
+        s->objs.push_back(ob);
+    }
+    if (nt != d->n_tri || ns != d->n_sph || nc != d->n_cyl) return bad("objects do not cover the primitive arrays");
+    if (accel_mode == 1) {
+        for (Object &ob : s->objs) {
+            if (ob.kind != RT_OBJ_MESH || ob.count < 8) continue;
+            s->mesh_accel.emplace_back();
+            MeshAccel &acc = s->mesh_accel.back();
+            acc.nodes.reserve((size_t)ob.count * 2 + 2);
+            std::vector<int> faces(ob.count);
+            for (int f = 0; f < ob.count; f++) faces[f] = f;
+            BvhBuilder b{s->tris, ob.first, acc, 0x1234567U + (uint32_t)ob.first};
+            acc.root = b.build(faces);
+            ob.accel_idx = (int)s->mesh_accel.size() - 1;
+        }
+    }
+    *out = s;
+    return RT_OK;
+}
+
+void orc_scene_destroy(orc_scene *s) { delete s; }
+
+// main.rs:28-44 (accumulation only; the division by NS and the gamma are orc_resolve)
+int32_t orc_render(orc_scene *s, const rt_camera *cam, const rt_params *pr, float *accum_rgb, rt_stats *stats, int32_t n_threads) {
+    if (!s || !cam || !pr || !accum_rgb) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*pr);
+    if (rc) return rc;
+    rc = check_supported(*s, *pr);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    uint64_t tot_closest = 0, tot_shadow = 0, tot_nodes = 0, tot_tris = 0, tot_cam = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    const int W = pr->width, H = pr->height;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : tot_closest, tot_shadow, tot_nodes, tot_tris, tot_cam)
+    for (int y = 0; y < H; y++) {
+        Counters cn;
+        uint64_t cams = 0;
+        for (int x = 0; x < W; x++) {
+            if (!pixel_selected(*pr, x, y)) continue;
+            uint32_t pixel = (uint32_t)(y * W + x);
+            uint32_t pk = pixel_key(pr->seed, pixel);
+            Ctx cx{*s, *pr, pk, &cn};
+            V3 col = BLACK;
+            for (int k = pr->spp_begin; k < pr->spp_end; k++) {
+                uint32_t nk = root_node_key((uint32_t)k);
+                Ray r;
+                if (!camera_sample(*cam, *pr, x, y, k, pk, nk, &r)) continue;
+                cams++;
+                switch (pr->shader) {
+                case RT_SHADER_NORMAL: col = col + normal_shader(cx, r); break;
+                case RT_SHADER_WHITTED: col = col + whitted_trace_shader(cx, r, 0, nk); break;
+                case RT_SHADER_PATH: col = col + path_trace_shader(cx, r, 0, nk); break;
+                default: col = col + path_trace_shader_mis(cx, r, 0, nk); break;
+                }
+            }
+            float *dst = accum_rgb + 3 * (size_t)pixel;
+            dst[0] += col.x;
+            dst[1] += col.y;
+            dst[2] += col.z;
+        }
+        tot_closest += cn.closest;
+        tot_shadow += cn.shadow;
+        tot_nodes += cn.nodes;
+        tot_tris += cn.tris;
+        tot_cam += cams;
+    }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->camera_samples = tot_cam;
+        stats->rays_closest = tot_closest;
+        stats->rays_shadow = tot_shadow;
+        stats->nodes_visited = tot_nodes;
+        stats->tris_tested = tot_tris;
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RT_OK;
+}
+
+// prim id and t of world.objects.hit for sample spp_begin of every pixel
+int32_t orc_primary_hits(orc_scene *s, const rt_camera *cam, const rt_params *pr, int32_t *prim_id, float *t) {
+    if (!s || !cam || !pr || !prim_id || !t) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*pr);
+    if (rc) return rc;
+    const int W = pr->width, H = pr->height;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+        Counters cn;
+        for (int x = 0; x < W; x++) {
+            uint32_t pixel = (uint32_t)(y * W + x);
+            prim_id[pixel] = -1;
+            t[pixel] = 0.0f;
+            if (!pixel_selected(*pr, x, y)) continue;
+            uint32_t pk = pixel_key(pr->seed, pixel);
+            uint32_t nk = root_node_key((uint32_t)pr->spp_begin);
+            Ray r;
+            if (!camera_sample(*cam, *pr, x, y, pr->spp_begin, pk, nk, &r)) continue;
+            Hit rec;
+            if (world_hit(*s, r, pr->t_min, pr->t_max, &rec, &cn)) {
+                prim_id[pixel] = rec.prim;
+                t[pixel] = rec.t;
+            }
+        }
+    }
+    return RT_OK;
+}
+
+// main.rs:45-50
+int32_t orc_resolve(const float *accum_rgb, int64_t n_pixels, int32_t spp, int32_t *out_i32, uint8_t *rgb8) {
+    if (!accum_rgb || n_pixels < 0 || spp <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n_pixels * 3; i++) {
+        float c = accum_rgb[i] / (float)spp;
+        c = std::sqrt(c);
+        int32_t v = cast_i32(255.99f * c);
+        if (out_i32) out_i32[i] = v;
+        if (rgb8) rgb8[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------- known-answer probes
+void orc_camera_new(const float *from, const float *at, const float *vup, float vfov, float aspect, rt_camera *out) {
+    camera_new(v3(from[0], from[1], from[2]), v3(at[0], at[1], at[2]), v3(vup[0], vup[1], vup[2]), vfov, aspect, out);
+}
+void orc_get_ray(const rt_camera *cam, float s, float t, float *o, float *d) {
+    Ray r = get_ray(*cam, s, t);
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+    d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+}
+// closest hit of the world; returns 1 on hit.  out6 = p(3), n(3)
+int32_t orc_world_hit(orc_scene *s, const float *o, const float *d, float t_min, float t_max, float *t, int32_t *prim, float *out6) {
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    Hit rec;
+    Counters cn;
+    if (!world_hit(*s, r, t_min, t_max, &rec, &cn)) return 0;
+    *t = rec.t;
+    *prim = rec.prim;
+    if (out6) { out6[0] = rec.p.x; out6[1] = rec.p.y; out6[2] = rec.p.z; out6[3] = rec.n.x; out6[4] = rec.n.y; out6[5] = rec.n.z; }
+    return 1;
+}
+// triangle test in isolation (geometry.rs:29-63); v = 9 floats
+int32_t orc_tri_hit(const float *v, const float *o, const float *d, float t_min, float t_max, int32_t both, float *t) {
+    Tri tr{v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), v3(v[6], v[7], v[8]), 0};
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    Hit rec;
+    if (!tri_hit(tr, r, t_min, t_max, both != 0, &rec)) return 0;
+    *t = rec.t;
+    return 1;
+}
+float orc_tri_area(const float *v) { return Tri{v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), v3(v[6], v[7], v[8]), 0}.area(); }
+void orc_tri_normal(const float *v, float *n) {
+    V3 nn = Tri{v3(v[0], v[1], v[2]), v3(v[3], v[4], v[5]), v3(v[6], v[7], v[8]), 0}.normal();
+    n[0] = nn.x; n[1] = nn.y; n[2] = nn.z;
+}
+// the reference's own box test (mesh.rs:109-122, `tmax <= tmin` rejects) for the flat-box known answer
+int32_t orc_ref_hit_box(const float *mn, const float *mx, const float *o, const float *d, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    for (int a = 0; a < 3; a++) {
+        float t0 = fmin_((mn[a] - o[a]) / d[a], (mx[a] - o[a]) / d[a]);
+        float t1 = fmax_((mn[a] - o[a]) / d[a], (mx[a] - o[a]) / d[a]);
+        tmin = fmax_(t0, tmin);
+        tmax = fmin_(t1, tmax);
+        if (tmax <= tmin) return 0;
+    }
+    return 1;
+}
+int32_t orc_lights_hit(orc_scene *s, const float *o, const float *d, float t_min, float t_max, float *t) {
+    rt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.t_min = t_min;
+    pr.t_max = t_max;
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    return lights_hit(*s, r, pr, t);
+}
+float orc_lights_pdf(orc_scene *s, const float *o, const float *d, float t_min, float t_max) {
+    rt_params pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.t_min = t_min;
+    pr.t_max = t_max;
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    return lights_pdf(*s, r, pr);
+}
+void orc_light_info(orc_scene *s, int32_t i, float *area, float *normal) {
+    *area = s->lights[i].area;
+    normal[0] = s->lights[i].normal.x; normal[1] = s->lights[i].normal.y; normal[2] = s->lights[i].normal.z;
+}
+void orc_mat_brdf(const rt_material *m, const float *din, const float *dout, const float *n, float t_min, float *out) {
+    V3 r = mat_brdf(*m, v3(din[0], din[1], din[2]), v3(dout[0], dout[1], dout[2]), v3(n[0], n[1], n[2]), t_min);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float orc_mat_pdf(const rt_material *m, const float *din, const float *dout, const float *n, float t_min) {
+    return mat_pdf(*m, v3(din[0], din[1], din[2]), v3(dout[0], dout[1], dout[2]), v3(n[0], n[1], n[2]), t_min);
+}
+// scatter_d of a material at a hit point; returns 1 and the scattered direction when Some
+int32_t orc_mat_scatter_d(const rt_material *m, const float *o, const float *d, const float *p, const float *n, float t_min,
+                          uint32_t seed, uint32_t pixel, uint32_t sample, float *out_d) {
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    Hit rec;
+    rec.t = 0; rec.p = v3(p[0], p[1], p[2]); rec.n = v3(n[0], n[1], n[2]); rec.mat = 0; rec.prim = 0;
+    Ray s;
+    if (!mat_scatter_d(*m, r, rec, t_min, pixel_key(seed, pixel), root_node_key(sample), &s)) return 0;
+    out_d[0] = s.d.x; out_d[1] = s.d.y; out_d[2] = s.d.z;
+    return 1;
+}
+// counter RNG probes
+uint32_t orc_rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t branch_path_len, const uint32_t *branches,
+                     uint32_t purpose, uint32_t index) {
+    uint32_t nk = root_node_key(sample);
+    for (uint32_t i = 0; i < branch_path_len; i++) nk = child_node_key(nk, branches[i]);
+    Stream st(pixel_key(seed, pixel), nk, purpose);
+    uint32_t v = 0;
+    for (uint32_t i = 0; i <= index; i++) v = st.next_u32();
+    return v;
+}
+float orc_rng_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+void orc_sincos_2pi(float r, float *s, float *c) { sincos_2pi(r, s, c); }
+// points of a pixel/area sampler: out = 2 floats per point, returns the number of points
+int32_t orc_sampler_points(int32_t kind, float range, int32_t rate, uint32_t seed, uint32_t pixel, float *out) {
+    int n = 0;
+    uint32_t pk = pixel_key(seed, pixel);
+    for (int k = 0; k < rate; k++) {
+        Stream st(pk, root_node_key((uint32_t)k), P_CAMERA);
+        float a, b;
+        if (!sampler_point(kind, range, rate, k, st, &a, &b)) break;
+        out[2 * n] = a;
+        out[2 * n + 1] = b;
+        n++;
+    }
+    return n;
+}
+int32_t orc_disk_sample_d(int32_t kind, float radius, int32_t ns2, uint32_t seed, uint32_t pixel, uint32_t sample, float *ab) {
+    Stream st(pixel_key(seed, pixel), root_node_key(sample), P_NEE);
+    st.next_u32(); // the light pick precedes the point (LightList::visible_d)
+    return disk_sample_d(kind, radius, ns2, st, &ab[0], &ab[1]) ? 1 : 0;
+}
+int32_t orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"

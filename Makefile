@@ -1,0 +1,36 @@
+# Builds, in-tree:
+#   raytracer-rs_amd/lib/librt_hip.so   device library (HIP kernels for gfx950 + the C ABI of include/rt_api.h)
+#   raytracer-rs_amd/lib/librt_host.so  host scene library (include/rt_host.h)
+#   tools/rtcli                         command-line renderer, counterpart of the reference's src/bin/main.rs
+#   oracle/build/liboracle_rt.so        CPU oracle (test infrastructure only)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+PKG := raytracer-rs_amd
+LIBDIR := $(PKG)/lib
+CSRC := $(PKG)/csrc
+
+# -ffp-contract=off: geometry must round exactly like a scalar CPU evaluation (no FMA fusion).
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math -Wall -Wno-unused-parameter
+HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra
+
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so tools/rtcli oracle
+
+$(LIBDIR)/librt_hip.so: $(CSRC)/rt_kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/rt_bvh.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h include/rt_api.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_kernels.hip -x hip $(CSRC)/rt_api.cpp $(CSRC)/rt_bvh.cpp
+
+$(LIBDIR)/librt_host.so: $(PKG)/host/rt_host.cpp $(PKG)/host/rt_host.hpp include/rt_host.h include/rt_api.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(PKG)/host/rt_host.cpp
+
+tools/rtcli: tools/rtcli.cpp $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so
+	$(CXX) $(HOSTFLAGS) -o $@ tools/rtcli.cpp -L$(LIBDIR) -lrt_hip -lrt_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIBDIR) tools/rtcli oracle/build
+
+.PHONY: all oracle clean

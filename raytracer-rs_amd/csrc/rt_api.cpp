@@ -1,0 +1,601 @@
+// rt_api.cpp — the C ABI of include/rt_api.h: contexts, scene upload, the wavefront render loop.
+// Host code, compiled by hipcc.  Citations are paths under the reference root (raytracer-rs).
+
+#include "../../include/rt_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+#include "rt_kernels.h"
+
+using namespace rtd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    long long x = std::atoll(v);
+    return x > 0 ? (uint32_t)x : dflt;
+}
+
+} // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // queue pool, sized on demand
+    uint32_t capacity = 0, shadow_capacity = 0;
+    DevBuf<float4> qa[2], qb[2], qc[2], hit, sa, sb;
+    DevBuf<float2> sc2;
+    DevBuf<float> planes, accum_tmp;
+    DevBuf<int32_t> blocks, prim_tmp;
+    DevBuf<float> t_tmp;
+    Ctl *ctl = nullptr;      // device
+    Ctl *ctl_host = nullptr; // pinned
+    std::vector<hipEvent_t> events;
+};
+
+struct rt_scene {
+    rt_context *ctx = nullptr;
+    DevBuf<float4> nodes, tris, sph;
+    DevBuf<int2> sph_info, cyl_info;
+    DevBuf<float> cyl, ltris;
+    DevBuf<rt_material> mats;
+    DevBuf<DevLight> lights;
+    DevScene dev{};
+    bool has_microfacet = false, has_polygon_light = false;
+    int n_prims = 0;
+    int n_point_lights = 0, n_disk_lights = 0;
+};
+
+namespace {
+
+int set_device(rt_context *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+// lib.rs:31-34 on the host
+bool vec_eq3(const float *a, const float *b) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return dx * dx + dy * dy + dz * dz < 0.001f;
+}
+void tri_normal_area(const float *v, float *n, float *area) { // geometry.rs:16-26
+    float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+    float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    float len2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+    float inv = 1.0f / std::sqrt(len2);
+    n[0] = c[0] * inv; n[1] = c[1] * inv; n[2] = c[2] * inv;
+    *area = 0.5f * std::sqrt(len2);
+}
+
+int check_params(const rt_params &p) {
+    if (p.width <= 0 || p.height <= 0 || p.spp <= 0) return fail(RT_ERR_INVALID, "width, height and spp must be positive");
+    if ((long long)p.width * p.height > (1ll << 24)) return fail(RT_ERR_INVALID, "at most 2^24 pixels per frame");
+    if (p.spp_begin < 0 || p.spp_end < p.spp_begin || p.spp_end > p.spp) return fail(RT_ERR_INVALID, "bad sample range");
+    if (p.shader < RT_SHADER_NORMAL || p.shader > RT_SHADER_MIS) return fail(RT_ERR_INVALID, "bad shader");
+    if (p.pixel_sampler < RT_SAMPLER_WHITE || p.pixel_sampler > RT_SAMPLER_BLUE) return fail(RT_ERR_INVALID, "unexpected integer"); // sampler.rs:19
+    if (p.tile_size < 0 || (p.tile_size > 0 && (p.shard_count <= 0 || p.shard_rank < 0 || p.shard_rank >= p.shard_count)))
+        return fail(RT_ERR_INVALID, "bad tile sharding");
+    if (p.max_depth < 0 || p.max_depth > 62) return fail(RT_ERR_INVALID, "max_depth out of range");
+    if (p.light_samples < 0) return fail(RT_ERR_INVALID, "light_samples must be >= 0");
+    return RT_OK;
+}
+
+// combinations the reference stops on with assert!(false): material.rs:328-331,394-397, light.rs:292-301
+int check_supported(const rt_scene &s, const rt_params &p) {
+    if (p.shader == RT_SHADER_WHITTED && s.has_microfacet) return fail(RT_ERR_UNSUPPORTED, "whitted shader: Microfacet::scatter is not supported");
+    if (p.shader == RT_SHADER_WHITTED && s.has_polygon_light) return fail(RT_ERR_UNSUPPORTED, "whitted shader: PolygonLight::visible is not supported");
+    if (p.shader == RT_SHADER_PATH && s.has_microfacet) return fail(RT_ERR_UNSUPPORTED, "path shader: Microfacet::attenuation is not supported");
+    return RT_OK;
+}
+
+RenderConst make_const(const rt_camera &cam, const rt_params &p) {
+    RenderConst rc;
+    std::memset(&rc, 0, sizeof(rc));
+    rc.cam = cam;
+    rc.width = p.width; rc.height = p.height; rc.spp = p.spp; rc.spp_begin = p.spp_begin; rc.spp_end = p.spp_end;
+    rc.tile_size = p.tile_size; rc.shard_rank = p.shard_rank; rc.shard_count = p.shard_count;
+    rc.pixel_sampler = p.pixel_sampler; rc.light_samples = p.light_samples; rc.max_depth = p.max_depth;
+    rc.spp_edge = (int)std::sqrt((double)p.spp);           // sampler.rs:104
+    rc.ns2_edge = (int)std::sqrt((double)p.light_samples);
+    rc.t_min = p.t_min; rc.t_max = p.t_max; rc.seed = p.seed;
+    return rc;
+}
+
+bool pixel_selected_host(const rt_params &p, int x, int y) {
+    if (p.tile_size <= 0) return true;
+    int tiles_x = (p.width + p.tile_size - 1) / p.tile_size;
+    int t = (y / p.tile_size) * tiles_x + (x / p.tile_size);
+    return t % p.shard_count == p.shard_rank;
+}
+
+int ensure_queues(rt_context *ctx, uint32_t capacity, uint32_t shadow_capacity, size_t n_pixels) {
+    if (capacity > ctx->capacity) {
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx->qa[k].ensure(capacity));
+            HIP_TRY(ctx->qb[k].ensure(capacity));
+            HIP_TRY(ctx->qc[k].ensure(capacity));
+        }
+        HIP_TRY(ctx->hit.ensure(capacity));
+        ctx->capacity = capacity;
+    }
+    if (shadow_capacity > ctx->shadow_capacity) {
+        HIP_TRY(ctx->sa.ensure(shadow_capacity));
+        HIP_TRY(ctx->sb.ensure(shadow_capacity));
+        HIP_TRY(ctx->sc2.ensure(shadow_capacity));
+        ctx->shadow_capacity = shadow_capacity;
+    }
+    HIP_TRY(ctx->planes.ensure(3 * n_pixels));
+    return RT_OK;
+}
+
+struct StageTimer {
+    rt_context *ctx;
+    bool on;
+    size_t used = 0;
+    struct Span { int stage; size_t e0; };
+    std::vector<Span> spans;
+    double ms[4] = {0, 0, 0, 0};
+    hipEvent_t get() {
+        if (used == ctx->events.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ctx->events.push_back(e);
+        }
+        return ctx->events[used++];
+    }
+    void begin(int stage) {
+        if (!on) return;
+        spans.push_back({stage, used});
+        (void)hipEventRecord(get(), ctx->stream);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(get(), ctx->stream);
+    }
+    // call after a stream synchronisation
+    void collect() {
+        if (!on) return;
+        for (const Span &s : spans) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ctx->events[s.e0], ctx->events[s.e0 + 1]) == hipSuccess) ms[s.stage] += t;
+        }
+        spans.clear();
+        used = 0;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp) {
+    std::memset(p, 0, sizeof(*p));
+    p->width = width; p->height = height; p->spp = spp;
+    p->spp_begin = 0; p->spp_end = spp;
+    p->tile_size = 0; p->shard_rank = 0; p->shard_count = 1;
+    p->shader = RT_SHADER_MIS;
+    p->pixel_sampler = RT_SAMPLER_BLUE; // main.rs:31
+    p->light_samples = 9;               // NS2, lib.rs:24
+    p->max_depth = 40;                  // shader.rs:94
+    p->t_min = 0.001f; p->t_max = 10000000.0f; // lib.rs:17-18
+    p->seed = 1;
+    p->flags = 0;
+}
+
+int32_t rt_context_create(int32_t device_id, rt_context **out) {
+    if (!out) return fail(RT_ERR_INVALID, "null argument");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID, "no such device");
+    HIP_TRY(hipSetDevice(device_id));
+    rt_context *ctx = new rt_context();
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(Ctl), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_DEVICE, std::string("context creation: ") + hipGetErrorString(e));
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+int32_t rt_context_destroy(rt_context *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 2; k++) { ctx->qa[k].release(); ctx->qb[k].release(); ctx->qc[k].release(); }
+    ctx->hit.release(); ctx->sa.release(); ctx->sb.release(); ctx->sc2.release();
+    ctx->planes.release(); ctx->accum_tmp.release(); ctx->blocks.release(); ctx->prim_tmp.release(); ctx->t_tmp.release();
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->ctl) (void)hipFree(ctx->ctl);
+    if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+void *rt_context_stream(rt_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out) {
+    if (!ctx || !d || !out) return fail(RT_ERR_INVALID, "null argument");
+    if (d->n_tri < 0 || d->n_sph < 0 || d->n_cyl < 0 || d->n_mat < 0 || d->n_light < 0 || d->n_light_tri < 0 || d->n_obj < 0)
+        return fail(RT_ERR_INVALID, "negative count");
+    if (d->n_tri >= (1 << 25)) return fail(RT_ERR_INVALID, "too many triangles");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+
+    // world order -> primitive ids (hitable.rs:35-56: objects in list order, a mesh expanded in face_list order)
+    std::vector<int32_t> tri_prim(d->n_tri), sph_prim(d->n_sph), cyl_prim(d->n_cyl);
+    int prim = 0, nt = 0, ns = 0, nc = 0;
+    for (int i = 0; i < d->n_obj; i++) {
+        const rt_object &ob = d->objects[i];
+        switch (ob.kind) {
+        case RT_OBJ_TRIANGLE:
+            if (ob.first != nt || ob.count != 1 || nt + 1 > d->n_tri) return fail(RT_ERR_INVALID, "objects out of world order");
+            tri_prim[nt++] = prim++;
+            break;
+        case RT_OBJ_MESH:
+            if (ob.first != nt || ob.count < 0 || nt + ob.count > d->n_tri) return fail(RT_ERR_INVALID, "objects out of world order");
+            for (int f = 0; f < ob.count; f++) tri_prim[nt++] = prim++;
+            break;
+        case RT_OBJ_SPHERE:
+            if (ob.first != ns || ob.count != 1 || ns + 1 > d->n_sph) return fail(RT_ERR_INVALID, "objects out of world order");
+            sph_prim[ns++] = prim++;
+            break;
+        case RT_OBJ_CYLINDER:
+            if (ob.first != nc || ob.count != 1 || nc + 1 > d->n_cyl) return fail(RT_ERR_INVALID, "objects out of world order");
+            cyl_prim[nc++] = prim++;
+            break;
+        default: return fail(RT_ERR_INVALID, "bad object kind");
+        }
+    }
+    if (nt != d->n_tri || ns != d->n_sph || nc != d->n_cyl) return fail(RT_ERR_INVALID, "objects do not cover the primitive arrays");
+
+    bool has_mf = false;
+    auto mat_ok = [&](int m) {
+        if (m < 0 || m >= d->n_mat) return false;
+        has_mf |= d->mats[m].kind == RT_MAT_MICROFACET;
+        return true;
+    };
+    for (int i = 0; i < d->n_mat; i++)
+        if (d->mats[i].kind < RT_MAT_DIFFUSE || d->mats[i].kind > RT_MAT_MICROFACET) return fail(RT_ERR_INVALID, "bad material kind");
+    for (int i = 0; i < d->n_tri; i++) if (!mat_ok(d->tri_mat[i])) return fail(RT_ERR_INVALID, "no material"); // shader.rs:46,81,106
+    for (int i = 0; i < d->n_sph; i++) if (!mat_ok(d->sph_mat[i])) return fail(RT_ERR_INVALID, "no material");
+    for (int i = 0; i < d->n_cyl; i++) if (!mat_ok(d->cyl_mat[i])) return fail(RT_ERR_INVALID, "no material");
+
+    // lights: PolygonLight::new (light.rs:252-269)
+    std::vector<DevLight> lights(d->n_light);
+    bool has_poly = false;
+    for (int i = 0; i < d->n_light; i++) {
+        const rt_light &l = d->lights[i];
+        DevLight &L = lights[i];
+        std::memset(&L, 0, sizeof(L));
+        L.kind = l.kind;
+        L.ox = l.origin[0]; L.oy = l.origin[1]; L.oz = l.origin[2];
+        L.radius = l.radius;
+        L.sx = l.spectrum[0]; L.sy = l.spectrum[1]; L.sz = l.spectrum[2];
+        L.tri_first = l.tri_first; L.tri_count = l.tri_count; L.sampler_kind = l.sampler_kind;
+        if (l.kind == RT_LIGHT_POLYGON) {
+            has_poly = true;
+            if (l.tri_first < 0 || l.tri_count < 1 || l.tri_first + l.tri_count > d->n_light_tri) return fail(RT_ERR_INVALID, "polygon light: bad triangle range");
+            float n0[3], a0;
+            tri_normal_area(d->light_tri_v + 9 * (size_t)l.tri_first, n0, &a0);
+            float area = 0.0f;
+            for (int f = 0; f < l.tri_count; f++) {
+                float n[3], a;
+                tri_normal_area(d->light_tri_v + 9 * (size_t)(l.tri_first + f), n, &a);
+                area += a;
+                if (!vec_eq3(n0, n)) return fail(RT_ERR_INVALID, "the mesh of PolygonLight is not 2D!");
+            }
+            L.area = area;
+            L.nx = n0[0]; L.ny = n0[1]; L.nz = n0[2];
+        } else if (l.kind == RT_LIGHT_DISK) {
+            if (l.sampler_kind < RT_SAMPLER_WHITE || l.sampler_kind > RT_SAMPLER_BLUE) return fail(RT_ERR_INVALID, "unexpected integer");
+        } else if (l.kind != RT_LIGHT_POINT) return fail(RT_ERR_INVALID, "bad light kind");
+    }
+
+    rt_scene *s = new rt_scene();
+    s->ctx = ctx;
+    s->has_microfacet = has_mf;
+    s->has_polygon_light = has_poly;
+    s->n_prims = prim;
+    auto cleanup_fail = [&](hipError_t e, const char *what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        rt_scene_destroy(s);
+        return fail(RT_ERR_DEVICE, m);
+    };
+#define UP(buf, src, count, T)                                                                                       \
+    do {                                                                                                             \
+        size_t c_ = (size_t)(count);                                                                                 \
+        hipError_t e_ = (buf).ensure(c_ ? c_ : 1);                                                                   \
+        if (e_ == hipSuccess && c_) e_ = hipMemcpy((buf).p, (src), c_ * sizeof(T), hipMemcpyHostToDevice);           \
+        if (e_ != hipSuccess) return cleanup_fail(e_, #buf);                                                         \
+    } while (0)
+
+    BvhBuild bvh;
+    const int max_top = (int)env_u32("RT_BVH_TOP", 512);
+    build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, &bvh);
+    UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
+    UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
+    UP(s->sph, d->sph, d->n_sph, float4);
+    std::vector<int2> info(d->n_sph);
+    for (int i = 0; i < d->n_sph; i++) info[i] = make_int2(d->sph_mat[i], sph_prim[i]);
+    UP(s->sph_info, info.data(), d->n_sph, int2);
+    UP(s->cyl, d->cyl, 5 * (size_t)d->n_cyl, float);
+    info.resize(d->n_cyl);
+    for (int i = 0; i < d->n_cyl; i++) info[i] = make_int2(d->cyl_mat[i], cyl_prim[i]);
+    UP(s->cyl_info, info.data(), d->n_cyl, int2);
+    UP(s->mats, d->mats, d->n_mat, rt_material);
+    UP(s->lights, lights.data(), d->n_light, DevLight);
+    UP(s->ltris, d->light_tri_v, 9 * (size_t)d->n_light_tri, float);
+#undef UP
+
+    s->dev.nodes = s->nodes.p; s->dev.tris = s->tris.p; s->dev.sph = s->sph.p; s->dev.sph_info = s->sph_info.p;
+    s->dev.cyl = s->cyl.p; s->dev.cyl_info = s->cyl_info.p; s->dev.mats = s->mats.p; s->dev.lights = s->lights.p; s->dev.ltris = s->ltris.p;
+    s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
+    s->dev.n_light = d->n_light;
+    for (const DevLight &L : lights) { s->n_disk_lights += L.kind == RT_LIGHT_DISK; s->n_point_lights += L.kind == RT_LIGHT_POINT; }
+    *out = s;
+    return RT_OK;
+}
+
+int32_t rt_scene_destroy(rt_scene *s) {
+    if (!s) return RT_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    s->nodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
+    s->mats.release(); s->lights.release(); s->ltris.release();
+    delete s;
+    return RT_OK;
+}
+
+int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *accum_rgb, int32_t accum_is_device, rt_stats *stats) {
+    if (!s || !cam || !p || !accum_rgb) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*p);
+    if (rc) return rc;
+    rc = check_supported(*s, *p);
+    if (rc) return rc;
+    rt_context *ctx = s->ctx;
+    rc = set_device(ctx);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+
+    const size_t n_pixels = (size_t)p->width * p->height;
+    const RenderConst rcst = make_const(*cam, *p);
+    const int n_samples = p->spp_end - p->spp_begin;
+
+    // 8x8 pixel blocks to render: all of them, or those touching this shard's tiles
+    const uint32_t blocks_w = (uint32_t)((p->width + 7) / 8), blocks_h = (uint32_t)((p->height + 7) / 8);
+    uint32_t n_blocks = blocks_w * blocks_h;
+    const int32_t *blocks_dev = nullptr;
+    if (p->tile_size > 0) {
+        std::vector<int32_t> sel;
+        for (uint32_t by = 0; by < blocks_h; by++)
+            for (uint32_t bx = 0; bx < blocks_w; bx++) {
+                bool any = false;
+                for (int yy = 0; yy < 8 && !any; yy++)
+                    for (int xx = 0; xx < 8 && !any; xx++) {
+                        int x = (int)bx * 8 + xx, y = (int)by * 8 + yy;
+                        if (x < p->width && y < p->height && pixel_selected_host(*p, x, y)) any = true;
+                    }
+                if (any) sel.push_back((int32_t)(by * blocks_w + bx));
+            }
+        n_blocks = (uint32_t)sel.size();
+        HIP_TRY(ctx->blocks.ensure(std::max<size_t>(1, sel.size())));
+        if (!sel.empty()) HIP_TRY(hipMemcpyAsync(ctx->blocks.p, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // sel goes out of scope
+        blocks_dev = ctx->blocks.p;
+    }
+    const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
+
+    // queue geometry
+    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 21);
+    if (total < target) target = (uint32_t)std::max<unsigned long long>(total, 256ull);
+    target = (target + 255u) & ~255u;
+    const uint32_t capacity = 4u * target;
+    // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
+    // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
+    uint32_t per_node = 1;
+    if (p->shader == RT_SHADER_WHITTED) per_node = (uint32_t)std::max(1, s->n_point_lights + s->n_disk_lights * std::max(1, p->light_samples));
+    uint32_t max_process = capacity / 2;
+    uint32_t shadow_capacity = std::max<uint32_t>(capacity / 2, 256u);
+    if (per_node > 1) {
+        max_process = std::max<uint32_t>(256u, target / 2);
+        shadow_capacity = max_process * per_node;
+    }
+    rc = ensure_queues(ctx, capacity, shadow_capacity, n_pixels);
+    if (rc) return rc;
+
+    LaunchCfg cfg{ctx->stream, capacity, shadow_capacity, target, max_process};
+    HIP_TRY(hipMemsetAsync(ctx->planes.p, 0, 3 * n_pixels * sizeof(float), ctx->stream));
+
+    rt_stats st;
+    std::memset(&st, 0, sizeof(st));
+    StageTimer timer{ctx, (p->flags & RT_FLAG_TIMING) != 0};
+    const bool count_work = (p->flags & RT_FLAG_COUNT_WORK) != 0;
+
+    if (p->shader == RT_SHADER_NORMAL) {
+        timer.begin(1);
+        launch_normal_shader(cfg, s->dev, rcst, ctx->planes.p, (uint32_t)n_pixels);
+        timer.end();
+        st.launches_shade = 1;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        timer.collect();
+    } else {
+        Ctl init;
+        std::memset(&init, 0, sizeof(init));
+        init.total = total;
+        *ctx->ctl_host = init;
+        HIP_TRY(hipMemcpyAsync(ctx->ctl, ctx->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int cur = 0;
+        for (;;) {
+            launch_plan(cfg, ctx->ctl);
+            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            timer.collect();
+            const Ctl c = *ctx->ctl_host;
+            if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
+            if (c.done) break;
+            NodeQueue in{ctx->qa[cur].p, ctx->qb[cur].p, ctx->qc[cur].p};
+            NodeQueue out{ctx->qa[cur ^ 1].p, ctx->qb[cur ^ 1].p, ctx->qc[cur ^ 1].p};
+            ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
+            const uint32_t upper = c.n_in + c.n_new;
+            if (c.n_new) {
+                timer.begin(3);
+                launch_raygen(cfg, rcst, ctx->ctl, in, blocks_dev, n_blocks, blocks_w, c.n_new);
+                timer.end();
+                st.launches_raygen++;
+            }
+            const uint32_t n_proc = std::min(c.n_proc, upper);
+            if (n_proc) {
+                timer.begin(0);
+                launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, n_proc, count_work);
+                timer.end();
+                st.launches_extend++;
+            }
+            timer.begin(1);
+            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, upper);
+            timer.end();
+            st.launches_shade++;
+            if (p->shader != RT_SHADER_PATH && n_proc) {
+                timer.begin(2);
+                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels,
+                              (uint32_t)std::min<unsigned long long>((unsigned long long)n_proc * per_node, shadow_capacity), count_work);
+                timer.end();
+                st.launches_shadow++;
+            }
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+            cur ^= 1;
+        }
+        const Ctl c = *ctx->ctl_host;
+        st.camera_samples = c.cam_samples;
+        st.rays_closest = c.rays_closest;
+        st.rays_shadow = c.rays_shadow;
+        st.nodes_visited = c.nodes;
+        st.tris_tested = c.tris;
+        st.iterations = c.iterations;
+    }
+
+    // add the planes into the caller's interleaved sum buffer
+    if (accum_is_device) {
+        launch_planes_to_rgb(cfg, ctx->planes.p, accum_rgb, (uint32_t)n_pixels);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+        HIP_TRY(ctx->accum_tmp.ensure(3 * n_pixels));
+        HIP_TRY(hipMemcpyAsync(ctx->accum_tmp.p, accum_rgb, 3 * n_pixels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        launch_planes_to_rgb(cfg, ctx->planes.p, ctx->accum_tmp.p, (uint32_t)n_pixels);
+        HIP_TRY(hipMemcpyAsync(accum_rgb, ctx->accum_tmp.p, 3 * n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render: ") + hipGetErrorString(le));
+
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.ms_extend = timer.ms[0]; st.ms_shade = timer.ms[1]; st.ms_shadow = timer.ms[2]; st.ms_raygen = timer.ms[3];
+    if (p->shader == RT_SHADER_NORMAL) {
+        st.camera_samples = 0; // not tracked by the single-kernel normal shader
+    }
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+int32_t rt_primary_hits(rt_scene *s, const rt_camera *cam, const rt_params *p, int32_t *prim_id, float *t) {
+    if (!s || !cam || !p || !prim_id || !t) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*p);
+    if (rc) return rc;
+    rt_context *ctx = s->ctx;
+    rc = set_device(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)p->width * p->height;
+    HIP_TRY(ctx->prim_tmp.ensure(n));
+    HIP_TRY(ctx->t_tmp.ensure(n));
+    LaunchCfg cfg{ctx->stream, 0, 0, 0, 0};
+    launch_primary_hits(cfg, s->dev, make_const(*cam, *p), ctx->prim_tmp.p, ctx->t_tmp.p);
+    HIP_TRY(hipMemcpyAsync(prim_id, ctx->prim_tmp.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(t, ctx->t_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+static int32_t cast_i32(float v) { // Rust `as i32`
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int32_t)(-2147483647 - 1);
+    return (int32_t)v;
+}
+
+int32_t rt_resolve(const float *accum_rgb, int64_t n_pixels, int32_t spp, int32_t *out_i32, uint8_t *rgb8) {
+    if (!accum_rgb || n_pixels < 0 || spp <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n_pixels * 3; i++) {
+        float c = accum_rgb[i] / (float)spp; // main.rs:45
+        c = std::sqrt(c);                    // main.rs:46
+        int32_t v = cast_i32(255.99f * c);   // main.rs:48-50
+        if (out_i32) out_i32[i] = v;
+        if (rgb8) rgb8[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+    return RT_OK;
+}
+
+int32_t rt_resolve_device(rt_context *ctx, const float *accum_rgb_dev, int64_t n_pixels, int32_t spp, uint8_t *rgb8_dev) {
+    if (!ctx || !accum_rgb_dev || !rgb8_dev || n_pixels < 0 || spp <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    launch_resolve(ctx->stream, accum_rgb_dev, n_pixels, spp, rgb8_dev);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+} // extern "C"

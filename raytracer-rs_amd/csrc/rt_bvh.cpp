@@ -1,0 +1,257 @@
+// rt_bvh.cpp — binned-SAH BVH over all world triangles, emitted as a threaded node array (see rt_bvh.h).
+
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <limits>
+
+namespace rtd {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int a = 0; a < 3; a++) { mn[a] = std::numeric_limits<float>::max(); mx[a] = -std::numeric_limits<float>::max(); }
+    }
+    void grow(const float *p) {
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    void grow(const Box &b) {
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+    }
+    float area() const {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (dx < 0) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct TmpNode {
+    Box box;
+    int left = -1, right = -1; // children (inner)
+    int first = 0, count = 0;  // triangle range in the permuted order (leaf)
+    int depth = 0;
+};
+
+struct Builder {
+    const float *tri_v;
+    int n;
+    std::vector<Box> tbox;
+    std::vector<float> centroid; // 3 per triangle
+    std::vector<int> order;
+    std::vector<TmpNode> nodes;
+    int max_depth = 0;
+
+    static constexpr int MAX_LEAF = 4;
+    static constexpr int BINS = 16;
+
+    int build(int first, int count, int depth) {
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        max_depth = std::max(max_depth, depth);
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        for (int i = first; i < first + count; i++) {
+            box.grow(tbox[order[i]]);
+            cbox.grow(&centroid[3 * order[i]]);
+        }
+        nodes[id].box = box;
+        nodes[id].depth = depth;
+        if (count <= MAX_LEAF && (count == 1 || depth > 48 || !worth_splitting(first, count, box, cbox))) {
+            nodes[id].first = first;
+            nodes[id].count = count;
+            return id;
+        }
+        int mid = split(first, count, box, cbox);
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        // fixed visiting order of the stackless walk: the child with the larger surface first
+        if (nodes[r].box.area() > nodes[l].box.area()) std::swap(l, r);
+        nodes[id].left = l;
+        nodes[id].right = r;
+        return id;
+    }
+
+    // for small leaves: does the best SAH split beat intersecting everything?
+    bool worth_splitting(int first, int count, const Box &box, const Box &cbox) {
+        float best_cost;
+        int axis, bin;
+        if (!best_split(first, count, box, cbox, &best_cost, &axis, &bin)) return false;
+        return best_cost < (float)count;
+    }
+
+    bool best_split(int first, int count, const Box &box, const Box &cbox, float *best_cost, int *best_axis, int *best_bin) {
+        float parent_area = box.area();
+        *best_cost = std::numeric_limits<float>::max();
+        *best_axis = -1;
+        if (parent_area <= 0.0f) return false;
+        for (int a = 0; a < 3; a++) {
+            float ext = cbox.mx[a] - cbox.mn[a];
+            if (!(ext > 0.0f)) continue;
+            Box bb[BINS];
+            int bc[BINS];
+            for (int b = 0; b < BINS; b++) { bb[b].reset(); bc[b] = 0; }
+            float scale = (float)BINS / ext;
+            for (int i = first; i < first + count; i++) {
+                int t = order[i];
+                int b = std::min(BINS - 1, std::max(0, (int)((centroid[3 * t + a] - cbox.mn[a]) * scale)));
+                bb[b].grow(tbox[t]);
+                bc[b]++;
+            }
+            float right_area[BINS];
+            int right_cnt[BINS];
+            Box acc;
+            acc.reset();
+            int cnt = 0;
+            for (int b = BINS - 1; b > 0; b--) {
+                acc.grow(bb[b]);
+                cnt += bc[b];
+                right_area[b] = acc.area();
+                right_cnt[b] = cnt;
+            }
+            acc.reset();
+            cnt = 0;
+            for (int b = 0; b < BINS - 1; b++) {
+                acc.grow(bb[b]);
+                cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                float cost = 1.0f + (acc.area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1]) / parent_area;
+                if (cost < *best_cost) { *best_cost = cost; *best_axis = a; *best_bin = b; }
+            }
+        }
+        return *best_axis >= 0;
+    }
+
+    int split(int first, int count, const Box &box, const Box &cbox) {
+        float cost;
+        int axis, bin;
+        if (best_split(first, count, box, cbox, &cost, &axis, &bin)) {
+            float ext = cbox.mx[axis] - cbox.mn[axis];
+            float scale = (float)BINS / ext;
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int t) {
+                int b = std::min(BINS - 1, std::max(0, (int)((centroid[3 * t + axis] - cbox.mn[axis]) * scale)));
+                return b <= bin;
+            });
+            int mid = (int)(it - order.begin());
+            if (mid > first && mid < first + count) return mid;
+        }
+        // all centroids coincide (or a degenerate box): halve the range in its current order
+        return first + count / 2;
+    }
+};
+
+inline float int_bits(int v) {
+    float f;
+    std::memcpy(&f, &v, 4);
+    return f;
+}
+
+} // namespace
+
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, BvhBuild *out) {
+    out->nodes.clear();
+    out->tris.clear();
+    out->n_nodes = out->n_top = out->max_depth = 0;
+    if (n_tri <= 0) return;
+
+    Builder b;
+    b.tri_v = tri_v;
+    b.n = n_tri;
+    b.tbox.resize(n_tri);
+    b.centroid.resize(3 * (size_t)n_tri);
+    b.order.resize(n_tri);
+    for (int t = 0; t < n_tri; t++) {
+        const float *v = tri_v + 9 * (size_t)t;
+        Box bx;
+        bx.reset();
+        bx.grow(v);
+        bx.grow(v + 3);
+        bx.grow(v + 6);
+        // Pad every triangle box: the exact triangle test may accept a hit that lies a rounding error outside the
+        // exact box (flat, axis-aligned faces have zero-thickness boxes), and culling must never lose such a hit.
+        float ext = std::max(std::max(bx.mx[0] - bx.mn[0], bx.mx[1] - bx.mn[1]), bx.mx[2] - bx.mn[2]);
+        float mag = 0.0f;
+        for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(bx.mn[a]), std::fabs(bx.mx[a])));
+        float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+        for (int a = 0; a < 3; a++) { bx.mn[a] -= pad; bx.mx[a] += pad; }
+        b.tbox[t] = bx;
+        for (int a = 0; a < 3; a++) b.centroid[3 * (size_t)t + a] = (v[a] + v[3 + a] + v[6 + a]) * (1.0f / 3.0f);
+        b.order[t] = t;
+    }
+    b.nodes.reserve(2 * (size_t)n_tri);
+    int root = b.build(0, n_tri, 0);
+    const int nn = (int)b.nodes.size();
+
+    // numbering: breadth-first for the first max_top nodes, depth-first (visiting order) for the rest
+    std::vector<int> index(nn, -1);
+    int next_index = 0;
+    {
+        std::deque<int> q;
+        q.push_back(root);
+        while (!q.empty() && next_index < max_top) {
+            int id = q.front();
+            q.pop_front();
+            index[id] = next_index++;
+            if (b.nodes[id].left >= 0) {
+                q.push_back(b.nodes[id].left);
+                q.push_back(b.nodes[id].right);
+            }
+        }
+    }
+    out->n_top = next_index;
+    {
+        std::vector<int> stack;
+        stack.push_back(root);
+        while (!stack.empty()) {
+            int id = stack.back();
+            stack.pop_back();
+            if (index[id] < 0) index[id] = next_index++;
+            if (b.nodes[id].left >= 0) {
+                stack.push_back(b.nodes[id].right);
+                stack.push_back(b.nodes[id].left);
+            }
+        }
+    }
+
+    // threading: miss(node) = first node of whatever follows the node's subtree in visiting order
+    out->nodes.assign(8 * (size_t)nn, 0.0f);
+    struct Item { int id, next; };
+    std::vector<Item> stack;
+    stack.push_back({root, -1});
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        const TmpNode &nd = b.nodes[it.id];
+        float *dst = &out->nodes[8 * (size_t)index[it.id]];
+        for (int a = 0; a < 3; a++) { dst[a] = nd.box.mn[a]; dst[4 + a] = nd.box.mx[a]; }
+        dst[7] = int_bits(it.next);
+        if (nd.left >= 0) {
+            dst[3] = int_bits(index[nd.left]);
+            stack.push_back({nd.left, index[nd.right]});
+            stack.push_back({nd.right, it.next});
+        } else {
+            dst[3] = int_bits(~(nd.first * 8 + (nd.count - 1)));
+        }
+    }
+
+    out->tris.resize(12 * (size_t)n_tri);
+    for (int i = 0; i < n_tri; i++) {
+        int t = b.order[i];
+        const float *v = tri_v + 9 * (size_t)t;
+        float *dst = &out->tris[12 * (size_t)i];
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+        dst[3] = int_bits(prim_id[t]);
+        dst[4] = v[3] - v[0]; dst[5] = v[4] - v[1]; dst[6] = v[5] - v[2]; // E1 = v1 - v0 (geometry.rs:30)
+        dst[7] = int_bits(mat[t]);
+        dst[8] = v[6] - v[0]; dst[9] = v[7] - v[1]; dst[10] = v[8] - v[2]; // E2 = v2 - v0 (geometry.rs:31)
+        dst[11] = 0.0f;
+    }
+    out->n_nodes = nn;
+    out->max_depth = b.max_depth;
+}
+
+} // namespace rtd

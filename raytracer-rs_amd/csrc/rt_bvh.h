@@ -1,0 +1,26 @@
+// rt_bvh.h — host-side builder of the threaded (stackless) BVH the device kernels walk.
+//
+// Takes the place of BVHTree::build_tree (src/mesh.rs:225-261) for ALL triangles of the world at once.  The
+// reference splits at the median of a random axis with one face per leaf; here the split is chosen by a binned
+// surface-area heuristic, leaves hold up to 4 faces, and the tree is laid out for a stack-free walk: every node
+// carries the index to continue with after a miss.  Only the set of triangles matters for results (the kernels apply
+// the reference's tie rule themselves), so the tree shape is free.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace rtd {
+
+struct BvhBuild {
+    std::vector<float> nodes; // 8 floats per node: bmin.xyz, link, bmax.xyz, miss (links stored as int bits)
+    std::vector<float> tris;  // 12 floats per triangle in leaf order: v0.xyz, prim, e1.xyz, mat, e2.xyz, 0
+    int n_nodes = 0;
+    int n_top = 0;            // nodes [0, n_top) are the breadth-first top of the tree
+    int max_depth = 0;
+};
+
+// tri_v: 9 floats per triangle; prim_id / mat per triangle.  max_top bounds n_top.
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, BvhBuild *out);
+
+} // namespace rtd

@@ -1,0 +1,636 @@
+// rt_device.h — device-side building blocks of the wavefront path tracer (gfx950).
+//
+// Everything that decides WHERE a path goes (hit tests, hit points, normals, sampled directions, random numbers) is
+// written with a fixed operation order, IEEE division/sqrt and no FMA contraction (the file is compiled with
+// -ffp-contract=off), so those values are bit-identical with a scalar CPU evaluation of the same formulas.
+// Citations are paths under the reference root (raytracer-rs).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_api.h"
+
+namespace rtd {
+
+// ------------------------------------------------------------------------------------------------ vector maths
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return F3{a.x / s, a.y / s, a.z / s}; }
+// cgmath 0.18: dot = (x*x' + y*y') + z*z'; normalize = v * (1/|v|); lerp = a + (b-a)*t
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ F3 normalize(F3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+__device__ __forceinline__ F3 lerp(F3 a, F3 b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ F3 mul_v(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; } // lib.rs:26-28
+__device__ __forceinline__ bool is_black(F3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+__device__ __forceinline__ bool all_finite(F3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+#define RTD_PI 3.14159265358979323846f
+#define RTD_ZERO 1.1920928955078125e-07f /* f32::EPSILON, lib.rs:19 */
+
+__device__ __forceinline__ bool vec_eq(F3 a, F3 b, float t_min) { // lib.rs:31-34
+    F3 d = a - b;
+    return dot(d, d) < t_min;
+}
+
+// ------------------------------------------------------------------------------------------------ counter RNG
+// value = f(seed, pixel, sample, path node, purpose, index): no state survives between draws.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t pixel_key(uint32_t seed, uint32_t pixel) { return mix32(mix32(seed ^ 0x9E3779B9U) + pixel); }
+__device__ __forceinline__ uint32_t root_node_key(uint32_t sample) { return mix32(sample + 0x6A09E667U); }
+__device__ __forceinline__ uint32_t child_node_key(uint32_t nk, uint32_t branch) { return mix32(nk + 0xBB67AE85U * (branch + 1U)); }
+
+enum : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_VISIBLE0 = 16 };
+
+struct Stream {
+    uint32_t pk, sk, j;
+    __device__ __forceinline__ Stream(uint32_t pk_, uint32_t nk, uint32_t purpose) : pk(pk_), sk(mix32(nk + 0x85EBCA6BU * purpose)), j(0) {}
+    __device__ __forceinline__ uint32_t next_u32() {
+        ++j;
+        return mix32((sk + 0x9E3779B9U * j) ^ pk);
+    }
+    // gen::<f32>() of rand 0.8.5: 24 bits scaled into [0,1)
+    __device__ __forceinline__ float next_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ uint32_t next_index(uint32_t n) { return __umulhi(next_u32(), n); }
+};
+
+// sin and cos of 2*pi*r, r in [0,1): exact quadrant reduction + fixed polynomials (plain mul/add, no libm call)
+__device__ __forceinline__ void sincos_2pi(float r, float *s_out, float *c_out) {
+    int q = (int)(r * 4.0f + 0.5f);
+    float f = r - (float)q * 0.25f;
+    float a = f * 6.28318530717958647692f;
+    float a2 = a * a;
+    float sp = -1.6666654611e-1f + a2 * (8.3321608736e-3f + a2 * -1.9515295891e-4f);
+    float s = a + a * a2 * sp;
+    float cp = 4.166664568298827e-2f + a2 * (-1.388731625493765e-3f + a2 * 2.443315711809948e-5f);
+    float c = 1.0f - 0.5f * a2 + a2 * a2 * cp;
+    switch (q & 3) {
+    case 0: *s_out = s; *c_out = c; break;
+    case 1: *s_out = c; *c_out = -s; break;
+    case 2: *s_out = -s; *c_out = -c; break;
+    default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scene on the device
+struct DevLight {
+    int32_t kind;
+    float ox, oy, oz;
+    float radius;
+    float sx, sy, sz;
+    int32_t tri_first, tri_count;
+    int32_t sampler_kind;
+    float area;       // PolygonLight::new, light.rs:252-269
+    float nx, ny, nz; // normal of face 0
+};
+
+// BVH node, 32 B: a = (bmin.xyz, link), b = (bmax.xyz, miss).  link >= 0: index of the first child (inner node);
+// link < 0: leaf holding triangles [first, first+count) with ~link = first*8 + (count-1).  miss = node to continue
+// with when the box is missed or the subtree/leaf is done (-1 = traversal finished).  Nodes [0, n_top) are the top of
+// the tree in breadth-first order (the part each workgroup keeps in LDS); the rest follow in depth-first order.
+// Triangle, 48 B: (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, unused) with e1 = v1-v0, e2 = v2-v0.
+struct DevScene {
+    const float4 *nodes;
+    const float4 *tris;
+    const float4 *sph;      // cx cy cz r
+    const int2 *sph_info;   // material, prim id
+    const float *cyl;       // 5 floats: cx cz ymin ymax r
+    const int2 *cyl_info;
+    const rt_material *mats;
+    const DevLight *lights;
+    const float *ltris;     // 9 floats per light triangle
+    int32_t n_nodes, n_top, n_tri, n_sph, n_cyl, n_light;
+};
+
+struct RenderConst {
+    rt_camera cam;
+    int32_t width, height, spp, spp_begin, spp_end;
+    int32_t tile_size, shard_rank, shard_count;
+    int32_t pixel_sampler, light_samples, max_depth;
+    int32_t spp_edge, ns2_edge; // floor(sqrt(spp)), floor(sqrt(light_samples)): UniformSampler::new, sampler.rs:104
+    float t_min, t_max;
+    uint32_t seed;
+};
+
+// hit codes written by the extend stage
+#define HIT_NONE (-1)
+#define HIT_KIND_TRI 0
+#define HIT_KIND_SPH 1
+#define HIT_KIND_CYL_SIDE 2
+#define HIT_KIND_CYL_TOP 3
+#define HIT_KIND_CYL_BOTTOM 4
+__device__ __forceinline__ int hit_code(int kind, int idx) { return (kind << 28) | idx; }
+__device__ __forceinline__ int hit_kind(int code) { return code >> 28; }
+__device__ __forceinline__ int hit_index(int code) { return code & 0x0FFFFFFF; }
+
+// ------------------------------------------------------------------------------------------------ primitives
+// geometry.rs:29-63 with E1, E2 precomputed (the same two subtractions, done once on the host)
+__device__ __forceinline__ bool tri_hit(F3 v0, F3 E1, F3 E2, F3 o, F3 d, float t_min, float t_max, bool both_side, float *t_out) {
+    F3 P = cross(d, E2);
+    float det = dot(P, E1);
+    if (!both_side && det < 0.0f) return false;
+    if (det == 0.0f) return false;
+    float inv_det = 1.0f / det;
+    F3 T = o - v0;
+    F3 Q = cross(T, E1);
+    float u = inv_det * dot(P, T);
+    if (u < 0.0f || u > 1.0f) return false;
+    float v = inv_det * dot(Q, d);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = inv_det * dot(Q, E2);
+    if (t < t_min || t > t_max) return false;
+    *t_out = t;
+    return true;
+}
+
+// geometry.rs:82-117
+__device__ __forceinline__ bool sph_hit(float4 s, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+    F3 oc = o - f3(s.x, s.y, s.z);
+    float a = dot(d, d);
+    float b = dot(oc, d);
+    float c = dot(oc, oc) - s.w * s.w;
+    float disc = b * b - a * c;
+    if (disc > t_min) {
+        float temp = (-b - sqrtf(b * b - a * c)) / a;
+        if (temp < t_max && temp > t_min) { *t_out = temp; return true; }
+        temp = (-b + sqrtf(b * b - a * c)) / a;
+        if (temp < t_max && temp > t_min) { *t_out = temp; return true; }
+    }
+    return false;
+}
+
+// geometry.rs:128-193; *kind receives HIT_KIND_CYL_*
+__device__ __forceinline__ bool cyl_hit(const float *cy, F3 o, F3 d, float t_min, float t_max, float *t_out, int *kind) {
+    const float cx = cy[0], cz = cy[1], ymin = cy[2], ymax = cy[3], r = cy[4];
+    float t_top = (ymax - o.y) / d.y;
+    float t_bottom = (ymin - o.y) / d.y;
+    F3 p_top = o + t_top * d;
+    float dtx = p_top.x - cx, dtz = p_top.z - cz;
+    bool hit_top = t_top > t_min && t_top < t_max && (dtx * dtx + dtz * dtz) < r * r;
+    F3 p_bottom = o + t_bottom * d;
+    float dbx = p_bottom.x - cx, dbz = p_bottom.z - cz;
+    bool hit_bottom = t_bottom > t_min && t_bottom < t_max && (dbx * dbx + dbz * dbz) < r * r;
+    float dx = d.x, dz = d.z;
+    float ox = o.x - cx, oz = o.z - cz;
+    float a = dx * dx + dz * dz;
+    float b = dx * ox + dz * oz;
+    float c = (ox * ox + oz * oz) - r * r;
+    float disc = b * b - a * c;
+    if (disc > t_min) {
+        float temp = (-b - sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) {
+            F3 p = o + temp * d;
+            if (p.y > ymin && p.y < ymax) { *t_out = temp; *kind = HIT_KIND_CYL_SIDE; return true; }
+        }
+        if (hit_top && t_top < t_bottom) { *t_out = t_top; *kind = HIT_KIND_CYL_TOP; return true; }
+        else if (hit_bottom) { *t_out = t_bottom; *kind = HIT_KIND_CYL_BOTTOM; return true; }
+        temp = (-b + sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) {
+            F3 p = o + temp * d;
+            if (p.y > ymin && p.y < ymax) { *t_out = temp; *kind = HIT_KIND_CYL_SIDE; return true; }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ BVH traversal
+// Stackless walk over the threaded node array.  The box test only culls (boxes are padded at build time and the exit
+// distance is widened), so it may use reciprocals; the triangle test is the exact one above.  Closest hit keeps, among
+// equal t, the triangle with the larger primitive id — the result of the reference's in-order scan, where a later
+// triangle replaces an earlier one at equal t (hitable.rs:44-50 with geometry.rs:53).
+struct TriHit {
+    float t;
+    int tri;  // index into DevScene::tris (-1 = none)
+    int prim; // primitive id
+};
+
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
+                                               uint32_t *n_nodes, uint32_t *n_tris) {
+    TriHit best{t_max, -1, -1};
+    if (sc.n_nodes == 0) return best;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    int node = 0;
+    while (node >= 0) {
+        float4 na, nb;
+        if (node < sc.n_top) {
+            na = lds_nodes[2 * node];
+            nb = lds_nodes[2 * node + 1];
+        } else {
+            na = sc.nodes[2 * node];
+            nb = sc.nodes[2 * node + 1];
+        }
+        if (COUNT) (*n_nodes)++;
+        float x0 = (na.x - o.x) * ix, x1 = (nb.x - o.x) * ix;
+        float y0 = (na.y - o.y) * iy, y1 = (nb.y - o.y) * iy;
+        float z0 = (na.z - o.z) * iz, z1 = (nb.z - o.z) * iz;
+        float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+        float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
+        int next = __float_as_int(nb.w);
+        if (tn <= tf * 1.00001f + 1e-7f) {
+            int link = __float_as_int(na.w);
+            if (link >= 0) {
+                next = link;
+            } else {
+                int packed = ~link;
+                int first = packed >> 3, count = (packed & 7) + 1;
+                for (int k = 0; k < count; k++) {
+                    const float4 *tp = sc.tris + 3 * (first + k);
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    if (COUNT) (*n_tris)++;
+                    float t;
+                    if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
+                        int prim = __float_as_int(a.w);
+                        if (ANY_HIT) {
+                            best.t = t; best.tri = first + k; best.prim = prim;
+                            return best;
+                        }
+                        if (t < best.t || (t == best.t && prim > best.prim)) {
+                            best.t = t; best.tri = first + k; best.prim = prim;
+                        }
+                    }
+                }
+            }
+        }
+        node = next;
+    }
+    return best;
+}
+
+// world.objects.hit (hitable.rs:35-62): triangles through the BVH, then spheres and cylinders in order.  A sphere or
+// cylinder needs t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.
+template <bool COUNT>
+__device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max, float *t_out,
+                                          int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
+    TriHit th = bvh_traverse<false, COUNT>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    float closest = th.t;
+    int code = th.tri >= 0 ? hit_code(HIT_KIND_TRI, th.tri) : HIT_NONE;
+    int prim = th.prim;
+    for (int i = 0; i < sc.n_sph; i++) {
+        float t;
+        if (sph_hit(sc.sph[i], o, d, t_min, closest, &t)) { closest = t; code = hit_code(HIT_KIND_SPH, i); prim = sc.sph_info[i].y; }
+    }
+    for (int i = 0; i < sc.n_cyl; i++) {
+        float t;
+        int kind;
+        if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, closest, &t, &kind)) { closest = t; code = hit_code(kind, i); prim = sc.cyl_info[i].y; }
+    }
+    *t_out = closest;
+    *code_out = code;
+    *prim_out = prim;
+}
+
+// occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)
+template <bool COUNT>
+__device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
+                                               uint32_t *n_nodes, uint32_t *n_tris) {
+    for (int i = 0; i < sc.n_sph; i++) {
+        float t;
+        if (sph_hit(sc.sph[i], o, d, t_min, t_max, &t)) return true;
+    }
+    for (int i = 0; i < sc.n_cyl; i++) {
+        float t;
+        int kind;
+        if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind)) return true;
+    }
+    TriHit th = bvh_traverse<true, COUNT>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    return th.tri >= 0;
+}
+
+// ------------------------------------------------------------------------------------------------ lights
+__device__ __forceinline__ F3 ltri_vertex(const DevScene &sc, int tri, int k) {
+    const float *p = sc.ltris + 9 * tri + 3 * k;
+    return f3(p[0], p[1], p[2]);
+}
+
+// NaiveMesh::hit_both_side over a light's faces (mesh.rs:66-82)
+__device__ __forceinline__ bool light_mesh_hit(const DevScene &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+    bool any = false;
+    float closest = t_max;
+    for (int f = 0; f < L.tri_count; f++) {
+        int tri = L.tri_first + f;
+        F3 v0 = ltri_vertex(sc, tri, 0);
+        F3 E1 = ltri_vertex(sc, tri, 1) - v0;
+        F3 E2 = ltri_vertex(sc, tri, 2) - v0;
+        float t;
+        if (tri_hit(v0, E1, E2, o, d, t_min, closest, true, &t)) { any = true; closest = t; }
+    }
+    *t_out = closest;
+    return any;
+}
+
+// Light::hit: light.rs:101-103, 223-238, 344-346
+__device__ __forceinline__ bool light_hit(const DevScene &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+    if (L.kind == RT_LIGHT_DISK) {
+        float hit_t = (L.oy - o.y) / d.y;
+        if (hit_t < t_min) return false;
+        float hx = o.x + hit_t * d.x;
+        float hz = o.z + hit_t * d.z;
+        float rx = hx - L.ox, rz = hz - L.oz;
+        if (rx * rx + rz * rz <= L.radius * L.radius) { *t_out = hit_t; return true; }
+        return false;
+    }
+    if (L.kind == RT_LIGHT_POLYGON) return light_mesh_hit(sc, L, o, d, t_min, t_max, t_out);
+    return false;
+}
+
+// LightList::_hit (light.rs:355-364): the FIRST light in list order that is hit, not the nearest
+__device__ __forceinline__ int lights_hit(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+    for (int i = 0; i < sc.n_light; i++) {
+        float t;
+        if (light_hit(sc, sc.lights[i], o, d, t_min, t_max, &t)) { *t_out = t; return i; }
+    }
+    return -1;
+}
+
+// light.rs:142-146
+__device__ __forceinline__ float disk_pdf(const DevLight &L, F3 dir, float sq_dist) {
+    float area = RTD_PI * (L.radius * L.radius);
+    float cosine = fabsf(dot(dir, f3(0.0f, 1.0f, 0.0f)));
+    return sq_dist / (cosine * area);
+}
+
+// Light::pdf once the light's own hit distance is known: light.rs:97-99, 215-221, 334-342
+__device__ __forceinline__ float light_pdf_with_t(const DevLight &L, F3 d, bool hit, float t) {
+    if (!hit || L.kind == RT_LIGHT_POINT) return RTD_ZERO;
+    float sq_dist = (t * t) * dot(d, d);
+    if (L.kind == RT_LIGHT_DISK) return disk_pdf(L, d, sq_dist);
+    float cosine = fabsf(dot(d, f3(L.nx, L.ny, L.nz)));
+    return sq_dist / (cosine * L.area);
+}
+
+// ------------------------------------------------------------------------------------------------ samplers
+__device__ __forceinline__ bool in_disk(float range, float a, float b) { // sampler.rs:273-277
+    float radius = range / 2.0f;
+    float dx = a - radius, dy = b - radius;
+    return dx * dx + dy * dy < radius * radius;
+}
+__device__ __forceinline__ float grid_coord(float interval, int m) { // sampler.rs:111,129-133: repeated addition
+    float v = interval / 2.0f;
+    for (int k = 0; k < m; k++) v += interval;
+    return v;
+}
+// k-th point of a fresh sampler (sampler.rs:34-269); false when the sampler yields fewer points
+__device__ __forceinline__ bool sampler_point(int kind, float range, int rate, int e, int k, Stream &st, float *a, float *b) {
+    if (kind == RT_SAMPLER_WHITE || kind == RT_SAMPLER_BLUE) {
+        if (k >= rate) return false;
+        *a = st.next_f32() * range;
+        *b = st.next_f32() * range;
+        return true;
+    }
+    if (k >= e * e) return false;
+    float interval = range / (float)e;
+    float gi = grid_coord(interval, k % e), gj = grid_coord(interval, k / e);
+    if (kind == RT_SAMPLER_UNIFORM) { *a = gi; *b = gj; return true; }
+    float jitter = interval / 2.0f;
+    *a = gi + st.next_f32() * jitter;
+    *b = gj + st.next_f32() * jitter;
+    return true;
+}
+// one point on a disk light for next-event estimation (DiskLight::visible_d, light.rs:183-213): the persistent
+// sampler of the reference becomes a stratum drawn from the path node's own stream
+__device__ __forceinline__ bool disk_sample_d(int kind, float radius, int ns2, int e, Stream &st, float *a, float *b) {
+    float range = radius * 2.0f;
+    if (kind == RT_SAMPLER_WHITE || kind == RT_SAMPLER_BLUE) {
+        for (int tries = 0; tries < 16; tries++) {
+            float pa = st.next_f32() * range, pb = st.next_f32() * range;
+            if (in_disk(range, pa, pb)) { *a = pa; *b = pb; return true; }
+        }
+        return false;
+    }
+    int n = e * e;
+    if (n <= 0) return false;
+    int k0 = (int)st.next_index((uint32_t)n);
+    for (int k = k0; k < n; k++) {
+        float pa, pb;
+        sampler_point(kind, range, ns2, e, k, st, &pa, &pb);
+        if (in_disk(range, pa, pb)) { *a = pa; *b = pb; return true; }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ materials
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return v - 2.0f * dot(v, n) * n; } // material.rs:36-38
+
+__device__ __forceinline__ F3 unit_vec_on_sphere(Stream &st) { // material.rs:123-136, at most 16 tries
+    float r1 = 0.0f, r2 = 0.0f, rsq = 0.0f;
+    for (int tries = 0; tries < 16; tries++) {
+        float a = 1.0f - 2.0f * st.next_f32();
+        float b = 1.0f - 2.0f * st.next_f32();
+        float q = a * a + b * b;
+        if (q < 1.0f) { r1 = a; r2 = b; rsq = q; break; }
+    }
+    float rh = 2.0f * sqrtf(1.0f - rsq);
+    return f3(r1 * rh, r2 * rh, 1.0f - 2.0f * rsq);
+}
+
+__device__ __forceinline__ bool refract(F3 v, F3 n, float ni_over_nt, float t_min, F3 *out) { // material.rs:171-180
+    F3 uv = normalize(v);
+    float dt = dot(uv, n);
+    float dd = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    if (dd > t_min) {
+        *out = ni_over_nt * (uv - n * dt) - n * sqrtf(dd);
+        return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ F3 albedo_of(const rt_material &m) { return f3(m.albedo[0], m.albedo[1], m.albedo[2]); }
+__device__ __forceinline__ F3 f0_of(const rt_material &m) { return f3(m.f0[0], m.f0[1], m.f0[2]); }
+
+__device__ __forceinline__ bool metal_brdf_ok(F3 din, F3 dout, F3 dnor, float t_min) { // material.rs:52-67
+    din = normalize(din);
+    dout = normalize(dout);
+    return fabsf(dot(din + dout, dnor)) < t_min;
+}
+__device__ __forceinline__ bool dielectric_brdf_ok(const rt_material &m, F3 din, F3 dout, F3 dnor, float t_min) { // material.rs:188-217
+    F3 outward;
+    float ni_over_nt;
+    if (dot(din, dnor) > t_min) { outward = -dnor; ni_over_nt = m.ref_idx; }
+    else { outward = dnor; ni_over_nt = 1.0f / m.ref_idx; }
+    din = normalize(din);
+    dout = normalize(dout);
+    F3 refracted;
+    if (refract(din, outward, ni_over_nt, t_min, &refracted)) return vec_eq(refracted, dout, t_min);
+    return fabsf(dot(din + dout, dnor)) < t_min;
+}
+
+// material.rs:275-303
+__device__ __forceinline__ float ggx_distribution(F3 n, F3 h, float alpha) {
+    float noh = dot(n, h);
+    float noh2 = noh * noh;
+    float alpha2 = alpha * alpha;
+    float e = noh2 * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (RTD_PI * (e * e));
+}
+__device__ __forceinline__ float ggx_schlick(float nov, float k) { return nov / (k + (1.0f - k) * nov); }
+__device__ __forceinline__ float ggx_partial_geometry_term(F3 l, F3 v, F3 n, float alpha) {
+    float nol = fabsf(dot(n, l));
+    float nov = fabsf(dot(n, v));
+    float r = sqrtf(alpha);
+    float k = ((r + 1.0f) * (r + 1.0f)) / 8.0f;
+    return ggx_schlick(nol, k) * ggx_schlick(nov, k);
+}
+__device__ __forceinline__ F3 fresnel_schlick(F3 din, F3 dnor, F3 f0) {
+    float a = 1.0f - fabsf(dot(dnor, din));
+    return lerp(f0, f3(1.0f, 1.0f, 1.0f), a * a);
+}
+
+__device__ __forceinline__ void get_local_coordinate(F3 v1, F3 *bx, F3 *by, F3 *bz) { // material.rs:314-323
+    v1 = normalize(v1);
+    F3 v2;
+    if (fabsf(v1.x) > fabsf(v1.y)) v2 = f3(-v1.z, 0.0f, v1.x) / sqrtf(v1.x * v1.x + v1.z * v1.z);
+    else v2 = f3(0.0f, v1.z, -v1.y) / sqrtf(v1.y * v1.y + v1.z * v1.z);
+    *bx = v2;
+    *by = v1;
+    *bz = cross(v1, v2);
+}
+
+// Material::brdf and Material::pdf evaluated together (both are always wanted for the same pair of directions):
+// material.rs:89-103, 153-160, 248-262, 361-391
+__device__ __forceinline__ void mat_brdf_pdf(const rt_material &m, F3 din, F3 dout, F3 dnor, float t_min, F3 *brdf, float *pdf) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE:
+        *brdf = albedo_of(m) / RTD_PI;
+        *pdf = 1.0f / RTD_PI;
+        return;
+    case RT_MAT_METAL: {
+        bool ok = metal_brdf_ok(din, dout, dnor, t_min);
+        *brdf = ok ? albedo_of(m) : f3(0.0f, 0.0f, 0.0f);
+        *pdf = ok ? 1.0f : RTD_ZERO;
+        return;
+    }
+    case RT_MAT_DIELECTRIC: {
+        bool ok = dielectric_brdf_ok(m, din, dout, dnor, t_min);
+        *brdf = ok ? f3(1.0f, 1.0f, 1.0f) : f3(0.0f, 0.0f, 0.0f);
+        *pdf = ok ? 1.0f : RTD_ZERO;
+        return;
+    }
+    default: {
+        F3 wg = normalize(dnor);
+        F3 wi = normalize(dout);
+        F3 wo = -normalize(din);
+        F3 wm = normalize(wi + wo);
+        float alpha = m.roughness * m.roughness;
+        {
+            float a2 = alpha * alpha;
+            float cos_theta = fabsf(dot(wg, wm));
+            float e = (a2 - 1.0f) * (cos_theta * cos_theta) + 1.0f;
+            float dd = a2 / (RTD_PI * (e * e));
+            *pdf = (dd * cos_theta) / (4.0f * fabsf(dot(wo, wm)));
+        }
+        if (dot(wi, wg) <= 0.0f || dot(wi, wm) <= 0.0f) { *brdf = f3(0.0f, 0.0f, 0.0f); return; }
+        F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
+        F3 f = fresnel_schlick(wi, wg, f0);
+        float dterm = ggx_distribution(wg, wm, alpha);
+        float g = ggx_partial_geometry_term(wi, wo, wg, alpha);
+        F3 res = (f * dterm * g) / (4.0f * fabsf(dot(wg, wi)) * fabsf(dot(wg, wo)));
+        *brdf = mul_v(albedo_of(m), res);
+        return;
+    }
+    }
+}
+
+// Material::attenuation: material.rs:105-107, 162-164, 264-266
+__device__ __forceinline__ F3 mat_attenuation(const rt_material &m) {
+    if (m.kind == RT_MAT_DIELECTRIC) return f3(1.0f, 1.0f, 1.0f);
+    return albedo_of(m);
+}
+
+// Material::scatter for Metal and Dielectric: material.rs:71-83, 221-242
+__device__ __forceinline__ bool mat_scatter_specular(const rt_material &m, F3 d_in, F3 n, float t_min, F3 *out) {
+    if (m.kind == RT_MAT_METAL) {
+        F3 reflected = reflect(normalize(d_in), n);
+        if (dot(reflected, n) > RTD_ZERO) { *out = reflected; return true; }
+        return false;
+    }
+    F3 reflected = reflect(d_in, n);
+    F3 outward;
+    float ni_over_nt;
+    if (dot(d_in, n) > t_min) { outward = -n; ni_over_nt = m.ref_idx; }
+    else { outward = n; ni_over_nt = 1.0f / m.ref_idx; }
+    F3 refracted;
+    if (refract(d_in, outward, ni_over_nt, t_min, &refracted)) *out = refracted;
+    else *out = reflected;
+    return true;
+}
+
+// Material::scatter_d: material.rs:85-87, 144-151, 244-246, 334-359
+__device__ __forceinline__ bool mat_scatter_d(const rt_material &m, F3 d_in, F3 n, float t_min, uint32_t pk, uint32_t nk, F3 *out) {
+    switch (m.kind) {
+    case RT_MAT_DIFFUSE: {
+        Stream st(pk, nk, P_SCATTER);
+        F3 d = unit_vec_on_sphere(st);
+        if (dot(d, n) < 0.0f) d = -d;
+        *out = d;
+        return true;
+    }
+    case RT_MAT_METAL:
+    case RT_MAT_DIELECTRIC: return mat_scatter_specular(m, d_in, n, t_min, out);
+    default: {
+        Stream st(pk, nk, P_SCATTER);
+        float r0 = st.next_f32();
+        float r1 = st.next_f32();
+        float a = m.roughness * m.roughness;
+        float a2 = a * a;
+        float cos_theta = sqrtf((1.0f - r0) / ((a2 - 1.0f) * r0 + 1.0f));
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        float sphi, cphi;
+        sincos_2pi(r1, &sphi, &cphi);
+        float x = sin_theta * cphi;
+        float y = cos_theta;
+        float z = sin_theta * sphi;
+        F3 bx, by, bz;
+        get_local_coordinate(n, &bx, &by, &bz);
+        F3 wm = normalize(x * bx + y * by + z * bz);
+        *out = reflect(d_in, wm);
+        return true;
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ camera
+__device__ __forceinline__ void get_ray(const rt_camera &c, float s, float t, F3 *o, F3 *d) { // camera.rs:29-34
+    F3 origin = f3(c.origin[0], c.origin[1], c.origin[2]);
+    F3 llc = f3(c.llc[0], c.llc[1], c.llc[2]);
+    F3 h = f3(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    F3 v = f3(c.vertical[0], c.vertical[1], c.vertical[2]);
+    *o = origin;
+    *d = llc + s * h + t * v - origin;
+}
+
+__device__ __forceinline__ bool pixel_selected(const RenderConst &rc, int x, int y) {
+    if (rc.tile_size <= 0) return true;
+    int tiles_x = (rc.width + rc.tile_size - 1) / rc.tile_size;
+    int t = (y / rc.tile_size) * tiles_x + (x / rc.tile_size);
+    return t % rc.shard_count == rc.shard_rank;
+}
+
+// one camera sample (main.rs:35-39): sub-pixel offset from the pixel sampler, then Camera::get_ray
+__device__ __forceinline__ bool camera_sample(const RenderConst &rc, int x, int y, int k, uint32_t pk, uint32_t nk, F3 *o, F3 *d) {
+    Stream st(pk, nk, P_CAMERA);
+    float a, b;
+    if (!sampler_point(rc.pixel_sampler, 1.0f, rc.spp, rc.spp_edge, k, st, &a, &b)) return false;
+    int i = x, j = rc.height - 1 - y;
+    float u = ((float)i + a) / (float)rc.width;
+    float v = ((float)j + b) / (float)rc.height;
+    get_ray(rc.cam, u, v, o, d);
+    return true;
+}
+
+} // namespace rtd

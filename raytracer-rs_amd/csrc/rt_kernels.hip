@@ -1,0 +1,609 @@
+// rt_kernels.hip — the wavefront stages as HIP kernels for gfx950 (wave64).
+//
+//   k_plan      one thread: closes the previous iteration's counters and decides how many camera rays to add
+//   k_raygen    camera ray generation (src/bin/main.rs:35-39, src/camera.rs:29-34), appended to the live queue
+//   k_extend    closest hit of world.objects + first light hit (src/shader.rs:99): stackless BVH walk with the top of
+//               the tree in LDS, then spheres / cylinders, then the light geometry
+//   k_shade     the body of the shaders (src/shader.rs:22-115, src/material.rs:400-484) in throughput form:
+//               emission, BSDF sampling + evaluation, next-event estimation; emits child nodes and shadow rays,
+//               compacted with wave ballots and one atomic per wave
+//   k_shadow    occlusion queries of the queued shadow rays (src/light.rs:74,170,200,320) + accumulation
+//
+// Built with -ffp-contract=off: see rt_device.h.
+
+#include "rt_kernels.h"
+
+namespace rtd {
+
+#define BLOCK 256
+
+// ---- wave-level queue append -------------------------------------------------------------------------------------
+// Every lane of the wave must call this (no early returns before it).  Returns the slot of this lane's element.
+__device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter, uint32_t *wave_total) {
+    unsigned long long mask = __ballot(valid);
+    uint32_t cnt = (uint32_t)__popcll(mask);
+    uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t base = 0;
+    if (cnt != 0) {
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    *wave_total = cnt;
+    return base + below;
+}
+
+__device__ __forceinline__ void add_pixel(float *planes, uint32_t n_pixels, uint32_t pixel, F3 c) {
+    atomicAdd(planes + pixel, c.x);
+    atomicAdd(planes + n_pixels + pixel, c.y);
+    atomicAdd(planes + 2u * n_pixels + pixel, c.z);
+}
+
+struct Node {
+    F3 o, d, w;
+    float b_pdf;
+    uint32_t meta, nk;
+};
+__device__ __forceinline__ uint32_t make_meta(uint32_t pixel, uint32_t depth, uint32_t root) { return pixel | (depth << 24) | (root << 30); }
+__device__ __forceinline__ void store_node(const NodeQueue &q, uint32_t i, const Node &n) {
+    q.a[i] = make_float4(n.o.x, n.o.y, n.o.z, n.d.x);
+    q.b[i] = make_float4(n.d.y, n.d.z, n.w.x, n.w.y);
+    q.c[i] = make_float4(n.w.z, n.b_pdf, __uint_as_float(n.meta), __uint_as_float(n.nk));
+}
+__device__ __forceinline__ Node load_node(const NodeQueue &q, uint32_t i) {
+    float4 a = q.a[i], b = q.b[i], c = q.c[i];
+    Node n;
+    n.o = f3(a.x, a.y, a.z);
+    n.d = f3(a.w, b.x, b.y);
+    n.w = f3(b.z, b.w, c.x);
+    n.b_pdf = c.y;
+    n.meta = __float_as_uint(c.z);
+    n.nk = __float_as_uint(c.w);
+    return n;
+}
+
+// ---- k_plan ---------------------------------------------------------------------------------------------------------
+__global__ void k_plan(Ctl *ctl, uint32_t capacity, uint32_t target, uint32_t max_process) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the iteration that just ran extended min(n_proc, n_in) nodes and queued n_shadow shadow rays
+    ctl->rays_closest += ctl->n_proc < ctl->n_in ? ctl->n_proc : ctl->n_in;
+    ctl->rays_shadow += ctl->n_shadow;
+    uint32_t n = ctl->n_out; // nodes alive
+    unsigned long long remaining = ctl->total - ctl->cursor;
+    uint32_t n_new = 0;
+    if (n < target && remaining > 0) {
+        unsigned long long room = target - n;
+        n_new = (uint32_t)(remaining < room ? remaining : room);
+    }
+    ctl->first = ctl->cursor;
+    ctl->cursor += n_new;
+    ctl->n_new = n_new;
+    ctl->n_in = n; // k_raygen appends its rays behind these
+    ctl->n_out = 0;
+    ctl->n_shadow = 0;
+    ctl->done = (n == 0 && n_new == 0) ? 1u : 0u;
+    if (!ctl->done) ctl->iterations++;
+    // how many of the queued nodes this iteration may shade: each can append two children, the rest is carried over
+    uint32_t upper = n + n_new; // raygen may produce fewer (pixels outside the frame / sampler exhausted)
+    uint32_t n_proc = upper;
+    if (n_proc > max_process) n_proc = max_process;
+    if (upper > capacity / 2) {
+        uint32_t room = capacity - upper;
+        if (n_proc > room) n_proc = room;
+        if (n_proc == 0) ctl->overflow = 1;
+    }
+    ctl->n_proc = n_proc;
+}
+
+// ---- k_raygen -------------------------------------------------------------------------------------------------------
+// Camera candidates are numbered sample-major: candidate c -> sample c / (n_blocks*64), 8x8 pixel block
+// (c / 64) % n_blocks, pixel c % 64 inside the block.  One wave = one 8x8 block of one sample.
+__global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t n_blocks,
+                                                  uint32_t blocks_w) {
+    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t n_new = ctl->n_new;
+    if (blockIdx.x * BLOCK >= n_new) return; // whole workgroup idle
+    bool valid = false;
+    Node n;
+    if (g < n_new) {
+        unsigned long long c = ctl->first + g;
+        unsigned long long per_sample = (unsigned long long)n_blocks * 64ull;
+        uint32_t s_rel = (uint32_t)(c / per_sample);
+        uint32_t r = (uint32_t)(c % per_sample);
+        uint32_t bi = r >> 6, lane = r & 63u;
+        uint32_t blk = blocks ? (uint32_t)blocks[bi] : bi;
+        int x = (int)((blk % blocks_w) * 8u + (lane & 7u));
+        int y = (int)((blk / blocks_w) * 8u + (lane >> 3));
+        int k = rc.spp_begin + (int)s_rel;
+        if (x < rc.width && y < rc.height && pixel_selected(rc, x, y)) {
+            uint32_t pixel = (uint32_t)(y * rc.width + x);
+            uint32_t pk = pixel_key(rc.seed, pixel);
+            uint32_t nk = root_node_key((uint32_t)k);
+            if (camera_sample(rc, x, y, k, pk, nk, &n.o, &n.d)) {
+                valid = true;
+                n.w = f3(1.0f, 1.0f, 1.0f);
+                n.b_pdf = 1.0f;
+                n.meta = make_meta(pixel, 0u, 1u);
+                n.nk = nk;
+            }
+        }
+    }
+    uint32_t cnt;
+    uint32_t slot = wave_append(valid, &ctl->n_in, &cnt);
+    if (valid) store_node(in, slot, n);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctl->cam_samples, (unsigned long long)cnt);
+}
+
+// ---- k_extend -------------------------------------------------------------------------------------------------------
+// hit record: (t_obj, object code, t_light, light index)
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit) {
+    extern __shared__ float4 lds_nodes[];
+    const uint32_t n_proc = min(ctl->n_proc, ctl->n_in);
+    if (blockIdx.x * BLOCK >= n_proc) return;
+    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_proc) return;
+    float4 a = in.a[i], b = in.b[i];
+    F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
+    float t_obj;
+    int code, prim;
+    uint32_t nn = 0, nt = 0;
+    world_hit<COUNT>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    float t_light = 0.0f;
+    int li = lights_hit(sc, o, d, rc.t_min, rc.t_max, &t_light);
+    hit[i] = make_float4(t_obj, __int_as_float(code), t_light, __int_as_float(li));
+    if (COUNT) {
+        atomicAdd(&ctl->nodes, (unsigned long long)nn);
+        atomicAdd(&ctl->tris, (unsigned long long)nt);
+    }
+}
+
+// ---- surface point ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void surface_at(const DevScene &sc, int code, F3 p, F3 *n, int *mat) {
+    int idx = hit_index(code);
+    switch (hit_kind(code)) {
+    case HIT_KIND_TRI: {
+        float4 b = sc.tris[3 * idx + 1], c = sc.tris[3 * idx + 2];
+        *n = normalize(cross(f3(b.x, b.y, b.z), f3(c.x, c.y, c.z))); // geometry.rs:59
+        *mat = __float_as_int(b.w);
+        break;
+    }
+    case HIT_KIND_SPH: {
+        float4 s = sc.sph[idx];
+        *n = (p - f3(s.x, s.y, s.z)) / s.w; // geometry.rs:94
+        *mat = sc.sph_info[idx].x;
+        break;
+    }
+    case HIT_KIND_CYL_SIDE: {
+        const float *cy = sc.cyl + 5 * idx;
+        *n = f3(p.x - cy[0], 0.0f, p.z - cy[1]) / cy[4]; // geometry.rs:155-156
+        *mat = sc.cyl_info[idx].x;
+        break;
+    }
+    case HIT_KIND_CYL_TOP:
+        *n = f3(0.0f, 1.0f, 0.0f);
+        *mat = sc.cyl_info[idx].x;
+        break;
+    default:
+        *n = f3(0.0f, -1.0f, 0.0f);
+        *mat = sc.cyl_info[idx].x;
+        break;
+    }
+}
+
+__device__ __forceinline__ F3 sample_in_triangle(const DevScene &sc, int tri, Stream &st) { // light.rs:274-288
+    float e1 = st.next_f32();
+    float e2 = st.next_f32();
+    float se1 = sqrtf(e1);
+    float bx = 1.0f - se1, by = e2 * se1;
+    return bx * ltri_vertex(sc, tri, 0) + by * ltri_vertex(sc, tri, 1) + (1.0f - bx - by) * ltri_vertex(sc, tri, 2);
+}
+
+// LightList::visible_d without the occlusion query (light.rs:387-397 -> 83-95, 183-213, 303-332): picks a light,
+// samples it, returns direction, radiance and the light's pdf.  The caller queues the shadow ray.
+__device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst &rc, F3 p, F3 n, uint32_t pk, uint32_t nk, F3 *dir_out,
+                                           F3 *radiance, float *p_light) {
+    if (sc.n_light == 0) return false;
+    Stream st(pk, nk, P_NEE);
+    const DevLight L = sc.lights[st.next_index((uint32_t)sc.n_light)];
+    F3 spectrum = f3(L.sx, L.sy, L.sz);
+    if (L.kind == RT_LIGHT_POINT) {
+        F3 dir = f3(L.ox, L.oy, L.oz) - p;
+        *dir_out = dir;
+        *radiance = spectrum * dot(normalize(dir), normalize(n)) / dot(dir, dir); // light.rs:79
+        *p_light = RTD_ZERO;
+        return true;
+    }
+    if (L.kind == RT_LIGHT_DISK) {
+        float a, b;
+        if (!disk_sample_d(L.sampler_kind, L.radius, rc.light_samples, rc.ns2_edge, st, &a, &b)) return false;
+        F3 origin = f3(L.ox, L.oy, L.oz) + f3(a - L.radius, 0.0f, b - L.radius);
+        F3 dir = origin - p;
+        float cs = dot(normalize(dir), normalize(n));
+        *dir_out = dir;
+        *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
+        *p_light = disk_pdf(L, dir, dot(dir, dir));
+        return true;
+    }
+    if (L.tri_count <= 0) return false;
+    int tri = L.tri_first + (int)st.next_index((uint32_t)L.tri_count);
+    F3 origin = sample_in_triangle(sc, tri, st);
+    F3 dir = origin - p;
+    float cs = dot(normalize(dir), normalize(n));
+    *dir_out = dir;
+    *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
+    float t_l;
+    bool h = light_mesh_hit(sc, L, p, dir, rc.t_min, rc.t_max, &t_l); // self.pdf(&r), light.rs:328,334-342
+    *p_light = light_pdf_with_t(L, dir, h, t_l);
+    return true;
+}
+
+// ---- k_shade ---------------------------------------------------------------------------------------------------------
+template <int SHADER>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
+                                                 ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t capacity, uint32_t shadow_capacity) {
+    const uint32_t n_in = ctl->n_in;
+    const uint32_t n_proc = min(ctl->n_proc, n_in);
+    if (blockIdx.x * BLOCK >= n_in) return;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+
+    bool have0 = false, have1 = false, have_s = false;
+    Node c0, c1;
+    F3 s_o, s_d, s_c;
+    uint32_t s_pixel = 0;
+    // Whitted's LightList::visible needs several shadow rays per surface point; they are produced after the main body
+    bool vis_pending = false;
+    F3 vis_p, vis_n, vis_w;
+    uint32_t vis_pk = 0, vis_nk = 0;
+
+    if (i >= n_proc && i < n_in) { // carried over unshaded: there was no room for its children this iteration
+        c0 = load_node(in, i);
+        have0 = true;
+    } else if (i < n_proc) {
+        Node nd = load_node(in, i);
+        const float4 h = hit[i];
+        const float t_obj = h.x, t_l = h.z;
+        const int code = __float_as_int(h.y), li = __float_as_int(h.w);
+        const uint32_t pixel = nd.meta & 0xFFFFFFu, depth = (nd.meta >> 24) & 63u, root = (nd.meta >> 30) & 1u;
+
+        // weight of this node: MIS divides by (light pdf + BSDF pdf) of the ray that led here (material.rs:465-467)
+        F3 beta = nd.w;
+        if (SHADER == RT_SHADER_MIS && !root) {
+            float l_pdf = li >= 0 ? light_pdf_with_t(sc.lights[li], nd.d, true, t_l) : RTD_ZERO; // LightList::pdf, light.rs:399-405
+            beta = nd.w / (l_pdf + nd.b_pdf);
+        }
+        const bool obj = code != HIT_NONE;
+        const bool light_wins = li >= 0 && (!obj || !(t_l > t_obj)); // shader.rs:101,108-112
+        if (light_wins) {
+            const DevLight &L = sc.lights[li];
+            add_pixel(planes, n_pixels, pixel, mul_v(beta, f3(L.sx, L.sy, L.sz)));
+        } else if (!obj) {
+            if (!all_finite(beta)) add_pixel(planes, n_pixels, pixel, beta * 0.0f); // 0 * inf, 0 * NaN of the recursive form
+        } else {
+            const F3 p = nd.o + t_obj * nd.d; // ray.rs:9-11
+            F3 n;
+            int mat_id;
+            surface_at(sc, code, p, &n, &mat_id);
+            const rt_material m = sc.mats[mat_id];
+            const uint32_t pk = pixel_key(rc.seed, pixel);
+
+            if (SHADER == RT_SHADER_MIS) {
+                F3 sd;
+                if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+                    F3 brdf;
+                    float pdf;
+                    mat_brdf_pdf(m, nd.d, sd, n, rc.t_min, &brdf, &pdf);
+                    F3 w = mul_v(beta, brdf);
+                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                        have0 = true;
+                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = pdf;
+                        c0.meta = make_meta(pixel, depth + 1u, 0u);
+                        c0.nk = child_node_key(nd.nk, 0u);
+                    }
+                }
+                if (m.kind == RT_MAT_MICROFACET) { // the diffuse lobe of material.rs:416-438
+                    Stream st(pk, nd.nk, P_DIFFUSE);
+                    F3 dd = unit_vec_on_sphere(st);
+                    if (dot(dd, n) < 0.0f) dd = -dd;
+                    F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
+                    F3 f = fresnel_schlick(dd, n, f0);
+                    F3 kd = (f3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
+                    F3 w = mul_v(beta, mul_v(kd, albedo_of(m) / RTD_PI));
+                    uint32_t dmin = (uint32_t)max(rc.max_depth - 6, 0); // depth.max(34) for the reference's 40
+                    uint32_t d1 = max(depth, dmin) + 1u;
+                    if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
+                        have1 = true;
+                        c1.o = p; c1.d = dd; c1.w = w; c1.b_pdf = 1.0f / RTD_PI;
+                        c1.meta = make_meta(pixel, d1, 0u);
+                        c1.nk = child_node_key(nd.nk, 1u);
+                    }
+                }
+                F3 ldir, radiance;
+                float p_l;
+                if (nee_sample(sc, rc, p, n, pk, nd.nk, &ldir, &radiance, &p_l)) { // material.rs:441-447, 473-480
+                    F3 brdf;
+                    float pdf;
+                    mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
+                    F3 direct = mul_v(radiance, brdf) / (p_l + pdf);
+                    F3 c = mul_v(beta, direct);
+                    if (!is_black(c)) {
+                        have_s = true;
+                        s_o = p; s_d = ldir; s_c = c; s_pixel = pixel;
+                    }
+                }
+            } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
+                F3 sd;
+                if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+                    F3 w = mul_v(beta, mat_attenuation(m));
+                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                        have0 = true;
+                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = 1.0f;
+                        c0.meta = make_meta(pixel, depth + 1u, 0u);
+                        c0.nk = child_node_key(nd.nk, 0u);
+                    }
+                }
+            } else { // RT_SHADER_WHITTED, shader.rs:32-45
+                F3 sd;
+                bool scat = (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) && mat_scatter_specular(m, nd.d, n, rc.t_min, &sd);
+                F3 w = mul_v(beta, mat_attenuation(m));
+                if (scat) {
+                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                        have0 = true;
+                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = 1.0f;
+                        c0.meta = make_meta(pixel, depth + 1u, 0u);
+                        c0.nk = child_node_key(nd.nk, 0u);
+                    }
+                } else if (!is_black(w)) {
+                    vis_pending = true;
+                    vis_p = p; vis_n = n; vis_w = w; vis_pk = pk; vis_nk = nd.nk;
+                    s_pixel = pixel;
+                }
+            }
+        }
+    }
+
+    // ---- compaction: children into the next queue, shadow rays into the shadow queue
+    uint32_t cnt0, cnt1, cnts;
+    uint32_t slot0 = wave_append(have0, &ctl->n_out, &cnt0);
+    uint32_t slot1 = wave_append(have1, &ctl->n_out, &cnt1);
+    if (have0) { if (slot0 < capacity) store_node(out, slot0, c0); else ctl->overflow = 1; }
+    if (have1) { if (slot1 < capacity) store_node(out, slot1, c1); else ctl->overflow = 1; }
+
+    if (SHADER == RT_SHADER_WHITTED) {
+        // LightList::visible (light.rs:368-385): every light; a disk light is sampled light_samples times (light.rs:150-181)
+        for (int l = 0; l < sc.n_light; l++) {
+            const DevLight L = sc.lights[l];
+            const F3 spectrum = f3(L.sx, L.sy, L.sz);
+            if (L.kind == RT_LIGHT_POINT) {
+                F3 dir = f3(L.ox, L.oy, L.oz) - vis_p;
+                F3 c = f3(0.0f, 0.0f, 0.0f);
+                if (vis_pending) c = mul_v(vis_w, spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)); // light.rs:79
+                bool v = vis_pending && !is_black(c);
+                uint32_t slot = wave_append(v, &ctl->n_shadow, &cnts);
+                if (v) {
+                    if (slot < shadow_capacity) {
+                        sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
+                        sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
+                        sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
+                    } else ctl->overflow = 1;
+                }
+            } else if (L.kind == RT_LIGHT_DISK) {
+                const float range = L.radius * 2.0f;
+                const bool white = L.sampler_kind == RT_SAMPLER_WHITE || L.sampler_kind == RT_SAMPLER_BLUE;
+                // first pass: how many of the sampler's points lie in the disk (actual_sample_num, light.rs:161-163)
+                int actual = 0;
+                if (vis_pending) {
+                    Stream st(vis_pk, vis_nk, P_VISIBLE0 + (uint32_t)l);
+                    for (int k = 0; k < rc.light_samples; k++) {
+                        float a, b;
+                        bool have = false;
+                        if (white) {
+                            for (int tries = 0; tries < 16 && !have; tries++) {
+                                a = st.next_f32() * range;
+                                b = st.next_f32() * range;
+                                have = in_disk(range, a, b);
+                            }
+                        } else {
+                            have = sampler_point(L.sampler_kind, range, rc.light_samples, rc.ns2_edge, k, st, &a, &b) && in_disk(range, a, b);
+                        }
+                        if (have) actual++;
+                    }
+                }
+                Stream st(vis_pk, vis_nk, P_VISIBLE0 + (uint32_t)l);
+                const float scale = RTD_PI * (L.radius * L.radius) / (float)actual;
+                for (int k = 0; k < rc.light_samples; k++) {
+                    float a = 0.0f, b = 0.0f;
+                    bool have = false;
+                    if (vis_pending) {
+                        if (white) {
+                            for (int tries = 0; tries < 16 && !have; tries++) {
+                                a = st.next_f32() * range;
+                                b = st.next_f32() * range;
+                                have = in_disk(range, a, b);
+                            }
+                        } else {
+                            have = sampler_point(L.sampler_kind, range, rc.light_samples, rc.ns2_edge, k, st, &a, &b) && in_disk(range, a, b);
+                        }
+                    }
+                    F3 origin = f3(L.ox, L.oy, L.oz) + f3(a - L.radius, 0.0f, b - L.radius);
+                    F3 dir = origin - vis_p;
+                    F3 c = f3(0.0f, 0.0f, 0.0f);
+                    if (have) c = mul_v(vis_w, (spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)) * scale); // light.rs:171,175-177
+                    bool v = have && !is_black(c);
+                    uint32_t slot = wave_append(v, &ctl->n_shadow, &cnts);
+                    if (v) {
+                        if (slot < shadow_capacity) {
+                            sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
+                            sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
+                            sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
+                        } else ctl->overflow = 1;
+                    }
+                }
+            }
+        }
+    } else {
+        uint32_t slot = wave_append(have_s, &ctl->n_shadow, &cnts);
+        if (have_s) {
+            if (slot < shadow_capacity) {
+                sh.a[slot] = make_float4(s_o.x, s_o.y, s_o.z, s_d.x);
+                sh.b[slot] = make_float4(s_d.y, s_d.z, s_c.x, s_c.y);
+                sh.c[slot] = make_float2(s_c.z, __uint_as_float(s_pixel));
+            } else ctl->overflow = 1;
+        }
+    }
+}
+
+// ---- k_shadow --------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels) {
+    extern __shared__ float4 lds_nodes[];
+    const uint32_t n = ctl->n_shadow;
+    if (blockIdx.x * BLOCK >= n) return;
+    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float4 a = sh.a[i], b = sh.b[i];
+    float2 c = sh.c[i];
+    F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
+    uint32_t nn = 0, nt = 0;
+    bool occ = world_occluded<COUNT>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
+    if (COUNT) {
+        atomicAdd(&ctl->nodes, (unsigned long long)nn);
+        atomicAdd(&ctl->tris, (unsigned long long)nt);
+    }
+}
+
+// ---- normal shader (shader.rs:7-13): no queues, one thread per pixel looping over its samples ---------------------------
+__global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderConst rc, float *planes, uint32_t n_pixels) {
+    extern __shared__ float4 lds_nodes[];
+    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+    __syncthreads();
+    const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
+    if (pixel >= n_pixels) return;
+    int x = (int)(pixel % (uint32_t)rc.width), y = (int)(pixel / (uint32_t)rc.width);
+    if (!pixel_selected(rc, x, y)) return;
+    uint32_t pk = pixel_key(rc.seed, pixel);
+    F3 col = f3(0.0f, 0.0f, 0.0f);
+    for (int k = rc.spp_begin; k < rc.spp_end; k++) {
+        F3 o, d;
+        if (!camera_sample(rc, x, y, k, pk, root_node_key((uint32_t)k), &o, &d)) continue;
+        float t;
+        int code, prim;
+        uint32_t nn, nt;
+        world_hit<false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t, &code, &prim, &nn, &nt);
+        if (code != HIT_NONE) {
+            F3 n;
+            int mat;
+            surface_at(sc, code, o + t * d, &n, &mat);
+            col = col + 0.5f * f3(n.x + 1.0f, n.y + 1.0f, n.z + 1.0f);
+        } else {
+            col = col + f3(0.8f, 0.8f, 0.8f);
+        }
+    }
+    planes[pixel] += col.x;
+    planes[n_pixels + pixel] += col.y;
+    planes[2u * n_pixels + pixel] += col.z;
+}
+
+// ---- primary-hit AOV -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_primary_hits(DevScene sc, RenderConst rc, int32_t *prim_out, float *t_out) {
+    extern __shared__ float4 lds_nodes[];
+    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+    __syncthreads();
+    const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
+    if (pixel >= (uint32_t)(rc.width * rc.height)) return;
+    int x = (int)(pixel % (uint32_t)rc.width), y = (int)(pixel / (uint32_t)rc.width);
+    int32_t prim = -1;
+    float t = 0.0f;
+    if (pixel_selected(rc, x, y)) {
+        F3 o, d;
+        if (camera_sample(rc, x, y, rc.spp_begin, pixel_key(rc.seed, pixel), root_node_key((uint32_t)rc.spp_begin), &o, &d)) {
+            int code, pr;
+            uint32_t nn, nt;
+            float th;
+            world_hit<false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &th, &code, &pr, &nn, &nt);
+            if (code != HIT_NONE) { prim = pr; t = th; }
+        }
+    }
+    prim_out[pixel] = prim;
+    t_out[pixel] = t;
+}
+
+// ---- accumulation buffer plumbing -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_planes_to_rgb(const float *planes, float *accum_rgb, uint32_t n_pixels) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_pixels) return;
+    accum_rgb[3u * i] += planes[i];
+    accum_rgb[3u * i + 1u] += planes[n_pixels + i];
+    accum_rgb[3u * i + 2u] += planes[2u * n_pixels + i];
+}
+
+// main.rs:45-50: /NS, sqrt, (255.99 * c) as i32, then clamped to a byte
+__global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long long n, float spp, uint8_t *rgb8) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float c = sqrtf(accum_rgb[i] / spp);
+    float v = 255.99f * c;
+    int iv = (v != v) ? 0 : (v >= 2147483648.0f ? 2147483647 : (v <= -2147483648.0f ? (-2147483647 - 1) : (int)v));
+    rgb8[i] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------------------
+static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
+static inline size_t lds_bytes(const DevScene &sc) { return (size_t)sc.n_top * 2 * sizeof(float4); }
+
+void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.capacity, cfg.target, cfg.max_process); }
+
+void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t n_blocks, uint32_t blocks_w,
+                   uint32_t n_threads) {
+    if (!n_threads) return;
+    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, rc, ctl, in, blocks, n_blocks, blocks_w);
+}
+
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t n_threads, bool count) {
+    if (!n_threads) return;
+    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit);
+}
+
+void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
+                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t n_threads) {
+    if (!n_threads) return;
+    dim3 g(nblocks(n_threads)), b(BLOCK);
+    if (shader == RT_SHADER_MIS)
+        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+    else if (shader == RT_SHADER_PATH)
+        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+    else
+        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+}
+
+void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
+                   uint32_t n_threads, bool count) {
+    if (!n_threads) return;
+    if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels);
+    else hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels);
+}
+
+void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels) {
+    hipLaunchKernelGGL(k_normal_shader, dim3(nblocks(n_pixels)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, planes, n_pixels);
+}
+
+void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t) {
+    uint32_t n = (uint32_t)(rc.width * rc.height);
+    hipLaunchKernelGGL(k_primary_hits, dim3(nblocks(n)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, prim, t);
+}
+
+void launch_planes_to_rgb(const LaunchCfg &cfg, const float *planes, float *accum_rgb, uint32_t n_pixels) {
+    hipLaunchKernelGGL(k_planes_to_rgb, dim3(nblocks(n_pixels)), dim3(BLOCK), 0, cfg.stream, planes, accum_rgb, n_pixels);
+}
+
+void launch_resolve(hipStream_t stream, const float *accum_rgb, int64_t n_pixels, int32_t spp, uint8_t *rgb8) {
+    long long n = (long long)n_pixels * 3;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, accum_rgb, n, (float)spp, rgb8);
+}
+
+} // namespace rtd

@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the GPU path tracer on the headline configuration.
+
+One step = one full render of the workload (every sample of every pixel) through rt_render, the per-rank sum buffers
+reduced to rank 0 with torch.distributed (RCCL) when more than one GPU takes part, and the 8-bit image resolved on
+rank 0.  The frame is split by sample range (rank r renders samples [r*S/N, (r+1)*S/N) of every pixel): total work is
+fixed, so scaling is "strong".  value = rays of all ranks (closest-hit + shadow queries) per second of the slowest rank.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, width, height, spp, shader)
+    "c1_cornell": ("cornell", 512, 512, 16, "mis"),
+    "c2_whitted": ("whitted", 1600, 1600, 16, "whitted"),
+    "c3_utah": ("utah", 1920, 1080, 256, "mis"),
+    "c4_miku": ("miku", 1920, 1080, 1024, "mis"),
+    "c5_composite": ("composite", 3840, 2160, 4096, "mis"),
+    "head": ("head", 800, 800, 800, "mis"),
+}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3_utah", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (invalidates the headline number)")
+    ap.add_argument("--shard", default="spp", choices=["spp", "tile"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rt = importlib.import_module("raytracer-rs_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    scene_name, W, H, spp, shader_name = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    shader = {"mis": rt.SHADER_MIS, "whitted": rt.SHADER_WHITTED, "path": rt.SHADER_PATH, "normal": rt.SHADER_NORMAL}[shader_name]
+
+    hs = rt.HostScene(scene_name, W / H)
+    ctx = rt.Context(local_rank)
+    t0 = time.perf_counter()
+    ds = rt.DeviceScene(ctx, hs.desc)
+    scene_ms = (time.perf_counter() - t0) * 1e3
+
+    plan = rt.plan_shards(args.shard, rank, world, spp, tile_size=64)
+    params = plan.apply(rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_TIMING))
+
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    hip = rt.hip_lib()
+
+    def step():
+        accum.zero_()
+        torch.cuda.synchronize()  # accum is zeroed on torch's stream, rt_render works on the context's stream
+        st = ds.render_device(hs.camera, params, accum.data_ptr())
+        rt.reduce_accum(accum, dst=0)
+        if rank == 0:
+            rc = hip.rt_resolve_device(ctx._h, accum.data_ptr(), W * H, spp, rgb8.data_ptr())
+            assert rc == 0, hip.rt_last_error()
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # aggregate over ranks: slowest rank's time, everyone's rays
+    rays_local = float(sum(s.rays_closest + s.rays_shadow for s in stats))
+    cam_local = float(sum(s.camera_samples for s in stats))
+    agg = torch.tensor([rays_local, cam_local], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays, total_cam = agg.tolist()
+    elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = elapsed / steps * 1e3
+        mrays = total_rays / elapsed / 1e6
+
+        # ---- roofline of the dominant kernel (k_extend: closest-hit traversal), from this rank's timed steps
+        ms_ext = sum(s.ms_extend for s in stats)
+        n_ext = sum(s.launches_extend for s in stats)
+        rays_ext = sum(s.rays_closest for s in stats)
+        stage_ms = {k: sum(getattr(s, "ms_" + k) for s in stats) / steps for k in ("extend", "shade", "shadow", "raygen")}
+        # mean BVH work per closest-hit ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
+        cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK)
+        cp.spp_begin, cp.spp_end = 0, 1
+        scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        cst = ds.render_device(hs.camera, cp, scratch.data_ptr())
+        n_rays_counted = max(1, cst.rays_closest + cst.rays_shadow)
+        nodes_per_ray = cst.nodes_visited / n_rays_counted
+        tris_per_ray = cst.tris_tested / n_rays_counted
+        d = hs.desc
+        bytes_per_ray = 32 + 16 + 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
+        roofline = None
+        if n_ext and ms_ext > 0:
+            avg_ms = ms_ext / n_ext
+            rays_per_launch = rays_ext / n_ext
+            achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                        "launches_per_step": n_ext / steps, "rays_per_launch": round(rays_per_launch, 1),
+                        "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
+                        "tris_per_ray": round(tris_per_ray, 2)}
+
+        # ---- CPU baseline: the oracle (a restatement of the reference, not the Rust binary) on a bounded sample
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py as orc
+
+            osc = orc.OracleScene(hs.desc, 1)
+            threads = min(orc.num_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
+            # calibrate on a coarse frame, then size the sample (same scene, camera and frame, first k samples per pixel
+            # of a sub-sampled frame) for about cpu_seconds of work
+            cw, ch = max(8, W // 8), max(8, H // 8)
+            pp = rt.default_params(cw, ch, spp, shader=shader, seed=1)
+            pp.spp_begin, pp.spp_end = 0, 1
+            t0 = time.perf_counter()
+            _, cs = osc.render(hs.camera, pp, threads=threads)
+            dt = max(time.perf_counter() - t0, 1e-3)
+            rate = (cs.rays_closest + cs.rays_shadow) / dt
+            scale = max(1.0, args.cpu_seconds / dt)
+            # grow the frame first (up to the full frame), then the number of samples
+            f = min(8.0, scale ** 0.5)
+            sw, sh_ = min(W, int(cw * f)), min(H, int(ch * f))
+            k = int(max(1, min(spp, round(scale / ((sw * sh_) / (cw * ch))))))
+            pp = rt.default_params(sw, sh_, spp, shader=shader, seed=1)
+            pp.spp_begin, pp.spp_end = 0, k
+            t0 = time.perf_counter()
+            _, cs = osc.render(hs.camera, pp, threads=threads)
+            dt = time.perf_counter() - t0
+            cpu_rays = cs.rays_closest + cs.rays_shadow
+            cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                   "sample": f"{scene_name} {sw}x{sh_}, samples 0..{k} of {spp} per pixel, {cpu_rays} rays in {dt:.1f} s "
+                             f"(C++ restatement of the reference with its median-split BVH; counts every ray the reference traces)"}
+
+        result = {
+            "metric": "Mrays/sec (whole node) + time-to-image, 1080p 256spp, 1/2/4/8 MI355X",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {scene_name} {W}x{H} {spp} spp, {shader_name} shader", "shard": args.shard,
+                       "rays_per_step": total_rays / steps, "camera_samples_per_step": total_cam / steps,
+                       "time_to_image_ms": round(ms_per_step, 2), "scene_upload_ms": round(scene_ms, 2),
+                       "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in stage_ms.items()}},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

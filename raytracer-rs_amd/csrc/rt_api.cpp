@@ -73,8 +73,8 @@ struct rt_context {
     DevBuf<float> planes, accum_tmp;
     DevBuf<int32_t> blocks, prim_tmp;
     DevBuf<float> t_tmp;
-    Ctl *ctl = nullptr;      // device
-    Ctl *ctl_host = nullptr; // pinned
+    Ctl *ctl = nullptr;          // device
+    CtlHead *ctl_host = nullptr; // pinned copy of the head
     std::vector<hipEvent_t> events;
 };
 
@@ -239,7 +239,7 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     ctx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(Ctl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
     if (e != hipSuccess) {
         delete ctx;
         return fail(RT_ERR_DEVICE, std::string("context creation: ") + hipGetErrorString(e));
@@ -437,25 +437,22 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
 
-    // queue geometry
+    // queue geometry: RT_NSEG segments per queue; a queue holds 4x the refill level so that bursts of branching
+    // (Microfacet spawns two rays per hit) fit; running out of room is reported, never silent
     uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 21);
-    if (total < target) target = (uint32_t)std::max<unsigned long long>(total, 256ull);
-    target = (target + 255u) & ~255u;
-    const uint32_t capacity = 4u * target;
     // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
     // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
     uint32_t per_node = 1;
     if (p->shader == RT_SHADER_WHITTED) per_node = (uint32_t)std::max(1, s->n_point_lights + s->n_disk_lights * std::max(1, p->light_samples));
-    uint32_t max_process = capacity / 2;
-    uint32_t shadow_capacity = std::max<uint32_t>(capacity / 2, 256u);
-    if (per_node > 1) {
-        max_process = std::max<uint32_t>(256u, target / 2);
-        shadow_capacity = max_process * per_node;
-    }
-    rc = ensure_queues(ctx, capacity, shadow_capacity, n_pixels);
+    if (per_node > 1) target = std::max<uint32_t>(1u << 16, target / 8);
+    if (total < target) target = (uint32_t)total;
+    target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
+    const uint32_t seg_capacity = 4u * target / RT_NSEG;
+    const uint32_t shadow_seg_capacity = (per_node > 1 ? 2u * target / RT_NSEG * per_node : seg_capacity);
+    rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, n_pixels);
     if (rc) return rc;
 
-    LaunchCfg cfg{ctx->stream, capacity, shadow_capacity, target, max_process};
+    LaunchCfg cfg{ctx->stream, seg_capacity, shadow_seg_capacity, target};
     HIP_TRY(hipMemsetAsync(ctx->planes.p, 0, 3 * n_pixels * sizeof(float), ctx->stream));
 
     rt_stats st;
@@ -470,47 +467,50 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         st.launches_shade = 1;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         timer.collect();
-    } else {
-        Ctl init;
-        std::memset(&init, 0, sizeof(init));
-        init.total = total;
-        *ctx->ctl_host = init;
-        HIP_TRY(hipMemcpyAsync(ctx->ctl, ctx->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, ctx->stream));
+    } else if (total > 0) {
+        HIP_TRY(hipMemsetAsync(ctx->ctl, 0, sizeof(Ctl), ctx->stream));
+        std::memset(ctx->ctl_host, 0, sizeof(CtlHead));
+        ctx->ctl_host->total = total;
+        ctx->ctl_host->per_sample = n_blocks * 64u;
+        HIP_TRY(hipMemcpyAsync(&ctx->ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int cur = 0;
         for (;;) {
             launch_plan(cfg, ctx->ctl);
-            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &ctx->ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             timer.collect();
-            const Ctl c = *ctx->ctl_host;
+            const CtlHead c = *ctx->ctl_host;
             if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
             if (c.done) break;
             NodeQueue in{ctx->qa[cur].p, ctx->qb[cur].p, ctx->qc[cur].p};
             NodeQueue out{ctx->qa[cur ^ 1].p, ctx->qb[cur ^ 1].p, ctx->qc[cur ^ 1].p};
             ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
-            const uint32_t upper = c.n_in + c.n_new;
             if (c.n_new) {
                 timer.begin(3);
-                launch_raygen(cfg, rcst, ctx->ctl, in, blocks_dev, n_blocks, blocks_w, c.n_new);
+                launch_raygen(cfg, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
                 timer.end();
                 st.launches_raygen++;
             }
-            const uint32_t n_proc = std::min(c.n_proc, upper);
-            if (n_proc) {
-                timer.begin(0);
-                launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, n_proc, count_work);
-                timer.end();
-                st.launches_extend++;
-            }
+            // most nodes any segment can hold after ray generation: what it carried in + its share of the raygen workgroups
+            const uint32_t new_blocks = (c.n_new + 255u) / 256u;
+            const uint32_t seg_threads = std::min(seg_capacity, c.max_in + ((new_blocks + RT_NSEG - 1) / RT_NSEG) * 256u);
+            timer.begin(0);
+            launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, seg_threads, count_work);
+            timer.end();
+            st.launches_extend++;
             timer.begin(1);
-            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, upper);
+            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, seg_threads);
             timer.end();
             st.launches_shade++;
-            if (p->shader != RT_SHADER_PATH && n_proc) {
+            if (p->shader != RT_SHADER_PATH) {
+                // shade workgroup (bx, s) appends to segment (bx + s) % RT_NSEG: a segment receives from at most
+                // ceil(blocks_x) * 1 workgroups per source segment, i.e. blocks_x * RT_NSEG / RT_NSEG * 256 * per_node rays
+                const uint32_t bx = (seg_threads + 255u) / 256u;
+                const unsigned long long bound = (unsigned long long)bx * 256ull * per_node;
                 timer.begin(2);
                 launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels,
-                              (uint32_t)std::min<unsigned long long>((unsigned long long)n_proc * per_node, shadow_capacity), count_work);
+                              (uint32_t)std::min<unsigned long long>(bound, shadow_seg_capacity), count_work);
                 timer.end();
                 st.launches_shadow++;
             }
@@ -518,7 +518,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
             cur ^= 1;
         }
-        const Ctl c = *ctx->ctl_host;
+        const CtlHead c = *ctx->ctl_host;
         st.camera_samples = c.cam_samples;
         st.rays_closest = c.rays_closest;
         st.rays_shadow = c.rays_shadow;
@@ -560,7 +560,7 @@ int32_t rt_primary_hits(rt_scene *s, const rt_camera *cam, const rt_params *p, i
     const size_t n = (size_t)p->width * p->height;
     HIP_TRY(ctx->prim_tmp.ensure(n));
     HIP_TRY(ctx->t_tmp.ensure(n));
-    LaunchCfg cfg{ctx->stream, 0, 0, 0, 0};
+    LaunchCfg cfg{ctx->stream, 0, 0, 0};
     launch_primary_hits(cfg, s->dev, make_const(*cam, *p), ctx->prim_tmp.p, ctx->t_tmp.p);
     HIP_TRY(hipMemcpyAsync(prim_id, ctx->prim_tmp.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(t, ctx->t_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

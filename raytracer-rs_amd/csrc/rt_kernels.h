@@ -24,39 +24,57 @@ struct ShadowQueue {
     float2 *c;
 };
 
-// Device-resident loop state, written by k_plan and the appending stages; the host only reads it back.
-struct Ctl {
-    uint32_t n_in;     // nodes in the current queue (after ray generation)
-    uint32_t n_out;    // nodes appended to the next queue so far
-    uint32_t n_shadow; // shadow rays queued this iteration
-    uint32_t n_new;    // camera candidates to generate this iteration
-    unsigned long long first;  // first camera candidate of this iteration
+// The queues are cut into NSEG equal segments, each with its own fill counter on its own 128-byte line: appends are
+// one returning atomic per workgroup, and a single counter word would serialise them (about 90 per microsecond).
+// Workgroup b of a producing kernel appends to segment b % NSEG; consumers run a (blocks, NSEG) grid.
+#define RT_NSEG 32
+
+struct SegCounter {
+    uint32_t v;
+    uint32_t pad[31];
+};
+
+// Device-resident loop state, written by k_plan and the appending stages; the host reads back the head only.
+struct CtlHead {
+    uint32_t n_alive;   // nodes carried into this iteration (before ray generation)
+    uint32_t n_new;     // camera candidates to generate this iteration
+    uint32_t max_in;    // largest per-segment node count before ray generation
+    uint32_t max_shadow_prev; // largest per-segment shadow count of the previous iteration (diagnostic)
+    uint32_t first_sample;    // sample index (relative to spp_begin) of the first camera candidate of this iteration
+    uint32_t first_rem;       // ... and its position inside that sample
+    uint32_t per_sample;      // camera candidates per sample = 64 * number of 8x8 pixel blocks
+    uint32_t iterations;
+    uint32_t done;      // nothing left to do
+    uint32_t overflow;  // a queue segment ran out of room (the render call fails)
+    uint32_t pad0, pad1;
     unsigned long long cursor; // next camera candidate not yet generated
     unsigned long long total;  // all camera candidates of this render call
     unsigned long long rays_closest, rays_shadow, cam_samples, nodes, tris;
-    uint32_t iterations;
-    uint32_t done;     // nothing left to do
-    uint32_t overflow; // a queue ran out of room (the render call fails)
-    uint32_t n_proc;   // nodes of the current queue that are extended and shaded this iteration; the rest is carried over
+};
+
+struct Ctl {
+    CtlHead h;
+    SegCounter seg_in[RT_NSEG];     // nodes per segment of the current queue
+    SegCounter seg_out[RT_NSEG];    // nodes appended per segment of the next queue
+    SegCounter seg_shadow[RT_NSEG]; // shadow rays per segment
 };
 
 struct LaunchCfg {
     hipStream_t stream;
-    uint32_t capacity;        // nodes per queue
-    uint32_t shadow_capacity; // shadow rays
-    uint32_t target;          // refill level: camera rays are generated while fewer nodes than this are alive
-    uint32_t max_process;     // most nodes one iteration may shade (bounds the appends of that iteration)
+    uint32_t seg_capacity;        // nodes per queue segment
+    uint32_t shadow_seg_capacity; // shadow rays per segment
+    uint32_t target;              // refill level: camera rays are generated while fewer nodes than this are alive
 };
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl);
-void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t n_blocks,
-                   uint32_t blocks_w, uint32_t n_threads);
-void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t n_threads,
+// seg_threads = upper bound of the elements in any one segment (the grid is ceil(seg_threads/256) x RT_NSEG)
+void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w, uint32_t n_threads);
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads,
                    bool count);
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out,
-                  const float4 *hit, ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t n_threads);
+                  const float4 *hit, ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_threads);
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                   uint32_t n_threads, bool count);
+                   uint32_t seg_threads, bool count);
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels);
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t);
 void launch_planes_to_rgb(const LaunchCfg &cfg, const float *planes, float *accum_rgb, uint32_t n_pixels);

@@ -17,9 +17,13 @@ namespace rtd {
 
 #define BLOCK 256
 
-// ---- wave-level queue append -------------------------------------------------------------------------------------
-// Every lane of the wave must call this (no early returns before it).  Returns the slot of this lane's element.
-__device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter, uint32_t *wave_total) {
+// ---- workgroup-level queue append ---------------------------------------------------------------------------------
+// Ballot + mbcnt give every lane its rank inside the wave; the four wave totals meet in LDS and ONE returning atomic
+// per workgroup reserves the slots in the segment's counter.  Every thread of the workgroup must call this, the
+// same number of times, with no divergent exit before it.  K = number of independent element streams appended at
+// once (child 0 + child 1 share a reservation; shadow rays use their own counter).
+// wave-level variant: one returning atomic per wave.  Every lane of the wave must call it.
+__device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter) {
     unsigned long long mask = __ballot(valid);
     uint32_t cnt = (uint32_t)__popcll(mask);
     uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -28,8 +32,41 @@ __device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter, u
         if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, cnt);
         base = __builtin_amdgcn_readfirstlane(base);
     }
-    *wave_total = cnt;
     return base + below;
+}
+
+struct BlockAppend {
+    uint32_t wave_cnt[BLOCK / 64][3];
+    uint32_t base[2];
+};
+
+// flags: a = first stream into counter A, b = second stream into counter A (placed after all of a), c = stream into counter B
+__device__ __forceinline__ void block_append3(BlockAppend &sm, bool a, bool b, bool c, uint32_t *counter_a, uint32_t *counter_b, uint32_t *slot_a,
+                                              uint32_t *slot_b, uint32_t *slot_c) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
+    const uint32_t below_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+    const uint32_t below_b = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+    const uint32_t below_c = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u));
+    if (lane == 0) {
+        sm.wave_cnt[wave][0] = (uint32_t)__popcll(ma);
+        sm.wave_cnt[wave][1] = (uint32_t)__popcll(mb);
+        sm.wave_cnt[wave][2] = (uint32_t)__popcll(mc);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tc = 0;
+        for (int w = 0; w < BLOCK / 64; w++) { ta += sm.wave_cnt[w][0] + sm.wave_cnt[w][1]; tc += sm.wave_cnt[w][2]; }
+        sm.base[0] = ta ? atomicAdd(counter_a, ta) : 0u;
+        sm.base[1] = tc ? atomicAdd(counter_b, tc) : 0u;
+    }
+    __syncthreads();
+    uint32_t oa = sm.base[0], oc = sm.base[1];
+    for (uint32_t w = 0; w < wave; w++) { oa += sm.wave_cnt[w][0] + sm.wave_cnt[w][1]; oc += sm.wave_cnt[w][2]; }
+    *slot_a = oa + below_a;
+    *slot_b = oa + sm.wave_cnt[wave][0] + below_b;
+    *slot_c = oc + below_c;
+    __syncthreads(); // sm may be reused by the next call
 }
 
 __device__ __forceinline__ void add_pixel(float *planes, uint32_t n_pixels, uint32_t pixel, F3 c) {
@@ -62,53 +99,66 @@ __device__ __forceinline__ Node load_node(const NodeQueue &q, uint32_t i) {
 }
 
 // ---- k_plan ---------------------------------------------------------------------------------------------------------
-__global__ void k_plan(Ctl *ctl, uint32_t capacity, uint32_t target, uint32_t max_process) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // the iteration that just ran extended min(n_proc, n_in) nodes and queued n_shadow shadow rays
-    ctl->rays_closest += ctl->n_proc < ctl->n_in ? ctl->n_proc : ctl->n_in;
-    ctl->rays_shadow += ctl->n_shadow;
-    uint32_t n = ctl->n_out; // nodes alive
-    unsigned long long remaining = ctl->total - ctl->cursor;
+__global__ void k_plan(Ctl *ctl, uint32_t target) {
+    if (blockIdx.x != 0) return;
+    __shared__ uint32_t s_in[RT_NSEG], s_out[RT_NSEG], s_sh[RT_NSEG];
+    const uint32_t t = threadIdx.x;
+    if (t < RT_NSEG) {
+        s_in[t] = ctl->seg_in[t].v;
+        s_out[t] = ctl->seg_out[t].v;
+        s_sh[t] = ctl->seg_shadow[t].v;
+        ctl->seg_in[t].v = s_out[t]; // the queue filled by the last iteration becomes the current one
+        ctl->seg_out[t].v = 0;
+        ctl->seg_shadow[t].v = 0;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    uint32_t prev_in = 0, alive = 0, prev_shadow = 0, max_in = 0, max_sh = 0;
+    for (int k = 0; k < RT_NSEG; k++) {
+        prev_in += s_in[k];
+        alive += s_out[k];
+        prev_shadow += s_sh[k];
+        max_in = s_out[k] > max_in ? s_out[k] : max_in;
+        max_sh = s_sh[k] > max_sh ? s_sh[k] : max_sh;
+    }
+    CtlHead &h = ctl->h;
+    // close the iteration that just ran: it extended prev_in nodes, n_alive of which were carried in, the rest new camera rays
+    h.rays_closest += prev_in;
+    h.rays_shadow += prev_shadow;
+    h.cam_samples += prev_in - h.n_alive;
+    unsigned long long remaining = h.total - h.cursor;
     uint32_t n_new = 0;
-    if (n < target && remaining > 0) {
-        unsigned long long room = target - n;
+    if (alive < target && remaining > 0) {
+        unsigned long long room = target - alive;
         n_new = (uint32_t)(remaining < room ? remaining : room);
     }
-    ctl->first = ctl->cursor;
-    ctl->cursor += n_new;
-    ctl->n_new = n_new;
-    ctl->n_in = n; // k_raygen appends its rays behind these
-    ctl->n_out = 0;
-    ctl->n_shadow = 0;
-    ctl->done = (n == 0 && n_new == 0) ? 1u : 0u;
-    if (!ctl->done) ctl->iterations++;
-    // how many of the queued nodes this iteration may shade: each can append two children, the rest is carried over
-    uint32_t upper = n + n_new; // raygen may produce fewer (pixels outside the frame / sampler exhausted)
-    uint32_t n_proc = upper;
-    if (n_proc > max_process) n_proc = max_process;
-    if (upper > capacity / 2) {
-        uint32_t room = capacity - upper;
-        if (n_proc > room) n_proc = room;
-        if (n_proc == 0) ctl->overflow = 1;
-    }
-    ctl->n_proc = n_proc;
+    h.first_sample = (uint32_t)(h.cursor / h.per_sample);
+    h.first_rem = (uint32_t)(h.cursor % h.per_sample);
+    h.cursor += n_new;
+    h.n_new = n_new;
+    h.n_alive = alive;
+    h.max_in = max_in;
+    h.max_shadow_prev = max_sh;
+    h.done = (alive == 0 && n_new == 0) ? 1u : 0u;
+    if (!h.done) h.iterations++;
 }
 
 // ---- k_raygen -------------------------------------------------------------------------------------------------------
-// Camera candidates are numbered sample-major: candidate c -> sample c / (n_blocks*64), 8x8 pixel block
-// (c / 64) % n_blocks, pixel c % 64 inside the block.  One wave = one 8x8 block of one sample.
-__global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t n_blocks,
-                                                  uint32_t blocks_w) {
+// Camera candidates are numbered sample-major: candidate c -> sample c / per_sample, 8x8 pixel block
+// (c % per_sample) / 64, pixel c % 64 inside the block.  One wave = one 8x8 block of one sample.
+__global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
+                                                  uint32_t seg_capacity) {
+    __shared__ BlockAppend sm;
     const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t n_new = ctl->n_new;
+    const uint32_t n_new = ctl->h.n_new;
     if (blockIdx.x * BLOCK >= n_new) return; // whole workgroup idle
     bool valid = false;
     Node n;
     if (g < n_new) {
-        unsigned long long c = ctl->first + g;
-        unsigned long long per_sample = (unsigned long long)n_blocks * 64ull;
-        uint32_t s_rel = (uint32_t)(c / per_sample);
-        uint32_t r = (uint32_t)(c % per_sample);
+        const uint32_t per_sample = ctl->h.per_sample;
+        uint32_t r = ctl->h.first_rem + g; // < 2^25 + 2^24
+        uint32_t s_rel = ctl->h.first_sample + r / per_sample;
+        r = r % per_sample;
         uint32_t bi = r >> 6, lane = r & 63u;
         uint32_t blk = blocks ? (uint32_t)blocks[bi] : bi;
         int x = (int)((blk % blocks_w) * 8u + (lane & 7u));
@@ -127,23 +177,29 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, Node
             }
         }
     }
-    uint32_t cnt;
-    uint32_t slot = wave_append(valid, &ctl->n_in, &cnt);
-    if (valid) store_node(in, slot, n);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&ctl->cam_samples, (unsigned long long)cnt);
+    const uint32_t seg = blockIdx.x % RT_NSEG;
+    uint32_t slot, s1, s2;
+    block_append3(sm, valid, false, false, &ctl->seg_in[seg].v, &ctl->seg_in[seg].v, &slot, &s1, &s2);
+    if (valid) {
+        if (slot < seg_capacity) store_node(in, seg * seg_capacity + slot, n);
+        else ctl->h.overflow = 1;
+    }
 }
 
 // ---- k_extend -------------------------------------------------------------------------------------------------------
+// grid (blocks, RT_NSEG): workgroup (bx, s) handles nodes [bx*256, bx*256+256) of segment s.
 // hit record: (t_obj, object code, t_light, light index)
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit) {
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t n_proc = min(ctl->n_proc, ctl->n_in);
-    if (blockIdx.x * BLOCK >= n_proc) return;
+    const uint32_t seg = blockIdx.y;
+    const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
+    if (blockIdx.x * BLOCK >= n_seg) return;
     for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
     __syncthreads();
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n_proc) return;
+    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    if (il >= n_seg) return;
+    const uint32_t i = seg * seg_capacity + il;
     float4 a = in.a[i], b = in.b[i];
     F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     float t_obj;
@@ -154,8 +210,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     int li = lights_hit(sc, o, d, rc.t_min, rc.t_max, &t_light);
     hit[i] = make_float4(t_obj, __int_as_float(code), t_light, __int_as_float(li));
     if (COUNT) {
-        atomicAdd(&ctl->nodes, (unsigned long long)nn);
-        atomicAdd(&ctl->tris, (unsigned long long)nt);
+        atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
+        atomicAdd(&ctl->h.tris, (unsigned long long)nt);
     }
 }
 
@@ -240,13 +296,19 @@ __device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst
 }
 
 // ---- k_shade ---------------------------------------------------------------------------------------------------------
+// grid (blocks, RT_NSEG) like k_extend.  Children go to segment (bx + s) % RT_NSEG of the next queue, which spreads
+// every segment's offspring over all segments and keeps them level.
 template <int SHADER>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
-                                                 ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t capacity, uint32_t shadow_capacity) {
-    const uint32_t n_in = ctl->n_in;
-    const uint32_t n_proc = min(ctl->n_proc, n_in);
-    if (blockIdx.x * BLOCK >= n_in) return;
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+                                                 ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
+                                                 uint32_t shadow_seg_capacity) {
+    __shared__ BlockAppend sm;
+    const uint32_t seg = blockIdx.y;
+    const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
+    if (blockIdx.x * BLOCK >= n_seg) return;
+    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t i = seg * seg_capacity + il;
+    const uint32_t oseg = (blockIdx.x + seg) % RT_NSEG;
 
     bool have0 = false, have1 = false, have_s = false;
     Node c0, c1;
@@ -257,10 +319,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     F3 vis_p, vis_n, vis_w;
     uint32_t vis_pk = 0, vis_nk = 0;
 
-    if (i >= n_proc && i < n_in) { // carried over unshaded: there was no room for its children this iteration
-        c0 = load_node(in, i);
-        have0 = true;
-    } else if (i < n_proc) {
+    if (il < n_seg) {
         Node nd = load_node(in, i);
         const float4 h = hit[i];
         const float t_obj = h.x, t_l = h.z;
@@ -364,11 +423,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     }
 
     // ---- compaction: children into the next queue, shadow rays into the shadow queue
-    uint32_t cnt0, cnt1, cnts;
-    uint32_t slot0 = wave_append(have0, &ctl->n_out, &cnt0);
-    uint32_t slot1 = wave_append(have1, &ctl->n_out, &cnt1);
-    if (have0) { if (slot0 < capacity) store_node(out, slot0, c0); else ctl->overflow = 1; }
-    if (have1) { if (slot1 < capacity) store_node(out, slot1, c1); else ctl->overflow = 1; }
+    uint32_t slot0, slot1, slot_s;
+    block_append3(sm, have0, have1, SHADER != RT_SHADER_WHITTED && have_s, &ctl->seg_out[oseg].v, &ctl->seg_shadow[oseg].v, &slot0, &slot1, &slot_s);
+    if (have0) { if (slot0 < seg_capacity) store_node(out, oseg * seg_capacity + slot0, c0); else ctl->h.overflow = 1; }
+    if (have1) { if (slot1 < seg_capacity) store_node(out, oseg * seg_capacity + slot1, c1); else ctl->h.overflow = 1; }
 
     if (SHADER == RT_SHADER_WHITTED) {
         // LightList::visible (light.rs:368-385): every light; a disk light is sampled light_samples times (light.rs:150-181)
@@ -380,13 +438,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                 F3 c = f3(0.0f, 0.0f, 0.0f);
                 if (vis_pending) c = mul_v(vis_w, spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)); // light.rs:79
                 bool v = vis_pending && !is_black(c);
-                uint32_t slot = wave_append(v, &ctl->n_shadow, &cnts);
+                uint32_t slot = wave_append(v, &ctl->seg_shadow[oseg].v);
                 if (v) {
-                    if (slot < shadow_capacity) {
+                    if (slot < shadow_seg_capacity) {
+                        slot += oseg * shadow_seg_capacity;
                         sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
                         sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
                         sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
-                    } else ctl->overflow = 1;
+                    } else ctl->h.overflow = 1;
                 }
             } else if (L.kind == RT_LIGHT_DISK) {
                 const float range = L.radius * 2.0f;
@@ -431,39 +490,43 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                     F3 c = f3(0.0f, 0.0f, 0.0f);
                     if (have) c = mul_v(vis_w, (spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)) * scale); // light.rs:171,175-177
                     bool v = have && !is_black(c);
-                    uint32_t slot = wave_append(v, &ctl->n_shadow, &cnts);
+                    uint32_t slot = wave_append(v, &ctl->seg_shadow[oseg].v);
                     if (v) {
-                        if (slot < shadow_capacity) {
+                        if (slot < shadow_seg_capacity) {
+                            slot += oseg * shadow_seg_capacity;
                             sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
                             sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
                             sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
-                        } else ctl->overflow = 1;
+                        } else ctl->h.overflow = 1;
                     }
                 }
             }
         }
     } else {
-        uint32_t slot = wave_append(have_s, &ctl->n_shadow, &cnts);
         if (have_s) {
-            if (slot < shadow_capacity) {
+            if (slot_s < shadow_seg_capacity) {
+                const uint32_t slot = oseg * shadow_seg_capacity + slot_s;
                 sh.a[slot] = make_float4(s_o.x, s_o.y, s_o.z, s_d.x);
                 sh.b[slot] = make_float4(s_d.y, s_d.z, s_c.x, s_c.y);
                 sh.c[slot] = make_float2(s_c.z, __uint_as_float(s_pixel));
-            } else ctl->overflow = 1;
+            } else ctl->h.overflow = 1;
         }
     }
 }
 
 // ---- k_shadow --------------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels) {
+__global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
+                                                  uint32_t shadow_seg_capacity) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t n = ctl->n_shadow;
+    const uint32_t seg = blockIdx.y;
+    const uint32_t n = min(ctl->seg_shadow[seg].v, shadow_seg_capacity);
     if (blockIdx.x * BLOCK >= n) return;
     for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
     __syncthreads();
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    if (il >= n) return;
+    const uint32_t i = seg * shadow_seg_capacity + il;
     float4 a = sh.a[i], b = sh.b[i];
     float2 c = sh.c[i];
     F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
@@ -471,8 +534,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     bool occ = world_occluded<COUNT>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
-        atomicAdd(&ctl->nodes, (unsigned long long)nn);
-        atomicAdd(&ctl->tris, (unsigned long long)nt);
+        atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
+        atomicAdd(&ctl->h.tris, (unsigned long long)nt);
     }
 }
 
@@ -555,37 +618,38 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long 
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
 static inline size_t lds_bytes(const DevScene &sc) { return (size_t)sc.n_top * 2 * sizeof(float4); }
 
-void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.capacity, cfg.target, cfg.max_process); }
+void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
 
-void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t n_blocks, uint32_t blocks_w,
-                   uint32_t n_threads) {
+void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w, uint32_t n_threads) {
     if (!n_threads) return;
-    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, rc, ctl, in, blocks, n_blocks, blocks_w);
+    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
 }
 
-void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t n_threads, bool count) {
-    if (!n_threads) return;
-    if (count) hipLaunchKernelGGL(k_extend<true>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit);
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads, bool count) {
+    if (!seg_threads) return;
+    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
+    if (count) hipLaunchKernelGGL(k_extend<true>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+    else hipLaunchKernelGGL(k_extend<false>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
-                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t n_threads) {
-    if (!n_threads) return;
-    dim3 g(nblocks(n_threads)), b(BLOCK);
+                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_threads) {
+    if (!seg_threads) return;
+    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
     if (shader == RT_SHADER_MIS)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
     else if (shader == RT_SHADER_PATH)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
     else
-        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.capacity, cfg.shadow_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
 }
 
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                   uint32_t n_threads, bool count) {
-    if (!n_threads) return;
-    if (count) hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels);
-    else hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(n_threads)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels);
+                   uint32_t seg_threads, bool count) {
+    if (!seg_threads) return;
+    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
+    if (count) hipLaunchKernelGGL(k_shadow<true>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+    else hipLaunchKernelGGL(k_shadow<false>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
 }
 
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels) {

@@ -255,6 +255,29 @@ def write_ppm(path: str, rgb_i32: np.ndarray) -> None:
 _hip = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch wheels carry their own libamdhip64.so (same soname as the system
+    one); if librt_hip.so pulled in the system copy first, a later `import torch` would find no GPU.  So when torch
+    is installed but not yet imported, its copy is loaded first and both sides resolve to it."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("RT_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def hip_lib() -> C.CDLL:
     """Loads librt_hip.so.  Raises ImportError if it has not been built: there is no CPU substitute."""
     global _hip
@@ -262,6 +285,7 @@ def hip_lib() -> C.CDLL:
         path = os.path.join(LIB_DIR, "librt_hip.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `make` at the repository root (needs hipcc)")
+        _share_hip_runtime_with_torch()
         lib = C.CDLL(path)
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_context_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
@@ -297,6 +321,9 @@ class Context:
     """One per device / process (rt_context_create)."""
 
     def __init__(self, device: int = 0):
+        import weakref
+
+        self._scenes = weakref.WeakSet()  # scenes must be destroyed before their context
         self._h = C.c_void_p()
         _check(hip_lib().rt_context_create(device, C.byref(self._h)))
         self.device = device
@@ -307,6 +334,8 @@ class Context:
 
     def close(self):
         if self._h:
+            for sc in list(self._scenes):
+                sc.close()
             hip_lib().rt_context_destroy(self._h)
             self._h = None
 
@@ -325,6 +354,7 @@ class DeviceScene:
         self._keep = keepalive
         self._h = C.c_void_p()
         _check(hip_lib().rt_scene_create(ctx._h, C.byref(desc), C.byref(self._h)))
+        ctx._scenes.add(self)
 
     def render(self, cam: Camera, params: Params, accum: Optional[np.ndarray] = None) -> Tuple[np.ndarray, Stats]:
         """Adds the selected samples into a host (H, W, 3) float32 sum buffer (created zeroed if None)."""

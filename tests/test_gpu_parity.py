@@ -1,0 +1,322 @@
+"""HIP path vs the CPU oracle, through the C ABI (ctypes -> librt_hip.so).  Needs an MI355X.
+
+Bars: primary-hit primitive ids and hit distances are BIT-EXACT.  Radiance sums: every random number, hit point,
+normal and sampled direction is bit-identical on both sides (same operation order, IEEE div/sqrt, no FMA), so paths
+are identical; only the order in which path weights are multiplied (recursive on the CPU, throughput form on the GPU)
+and the order of float additions into a pixel differ.  Tolerance per pixel channel: |gpu - cpu| <= 1e-4 * max(|cpu|, 1e-3)
+(observed: about 1e-6), NaN/Inf positions identical.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+FLOOR = 1e-3
+
+
+def assert_radiance_close(gpu, cpu, rel=REL):
+    assert gpu.shape == cpu.shape
+    assert np.array_equal(np.isnan(gpu), np.isnan(cpu)), "NaN positions differ"
+    assert np.array_equal(np.isinf(gpu), np.isinf(cpu)), "Inf positions differ"
+    fin = np.isfinite(cpu)
+    err = np.abs(gpu[fin] - cpu[fin]) / np.maximum(np.abs(cpu[fin]), FLOOR)
+    assert err.size == 0 or err.max() <= rel, f"max rel err {err.max():.3g}"
+
+
+GOLDEN = ["head_mis", "utah_mis", "cornell_mis", "mis_test_jittered", "light_test_uniform", "whitted_whitted", "whitted_path",
+          "whitted_normal", "blue_noise_test_whitted"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_against_committed_golden_vectors(rt, gpu_ctx, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"render_{name}.npz"))
+    meta = json.loads(str(g["meta"]))
+    hs = rt.HostScene(meta["scene"], meta["width"] / meta["height"])
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(meta["width"], meta["height"], meta["spp"], seed=meta["seed"], shader=meta["shader"], pixel_sampler=meta["pixel_sampler"])
+    prim, t = ds.primary_hits(hs.camera, p)
+    assert np.array_equal(prim, g["prim"])
+    assert np.array_equal(t, g["t"])
+    acc, st = ds.render(hs.camera, p)
+    assert_radiance_close(acc, g["accum"])
+    if meta["shader"] != rt.SHADER_NORMAL:
+        assert st.camera_samples == meta["width"] * meta["height"] * meta["spp"]
+        # the GPU prunes rays whose weight is exactly zero; it never traces more than the recursive form
+        assert 0 < st.rays_closest <= meta["rays_closest"] and st.rays_shadow <= meta["rays_shadow"]
+    ds.close()
+
+
+SWEEP = [
+    # scene, W, H, spp, overrides
+    ("head", 67, 45, 3, {"seed": 11}),                                             # ragged frame, odd spp
+    ("head", 32, 32, 9, {"pixel_sampler": 2}),                                      # uniform 3x3
+    ("head", 32, 32, 10, {"pixel_sampler": 3}),                                     # jittered: 9 of 10 samples exist, still /10
+    ("head", 32, 32, 5, {"pixel_sampler": 1, "max_depth": 3}),
+    ("head", 24, 24, 2, {"max_depth": 0}),
+    ("mis_test", 48, 32, 4, {"light_sampler": 1}),
+    ("mis_test", 48, 32, 4, {"light_sampler": 2}),
+    ("mis_test", 48, 32, 4, {"light_sampler": 3, "light_samples": 16}),
+    ("mis_test", 48, 32, 4, {"light_sampler": 4, "light_samples": 4}),
+    ("light_test", 64, 64, 4, {}),
+    ("composite", 48, 48, 2, {"seed": 3}),
+    ("miku", 64, 36, 2, {}),
+    ("whitted", 40, 40, 3, {"shader": 1, "light_sampler": 2}),
+    ("whitted", 40, 40, 3, {"shader": 1, "light_sampler": 3, "light_samples": 4}),
+    ("whitted", 40, 40, 3, {"shader": 1, "light_sampler": 1}),
+    ("blue_noise_test", 48, 48, 4, {"shader": 2}),
+    ("cornell", 32, 32, 2, {"shader": 2}),
+    ("cornell", 32, 32, 2, {"shader": 0}),
+]
+
+
+@pytest.mark.parametrize("scene,W,H,spp,kw", SWEEP)
+def test_live_oracle_sweep(rt, orc, gpu_ctx, scene, W, H, spp, kw):
+    kw = dict(kw)
+    hs = rt.HostScene(scene, W / H, light_sampler=kw.pop("light_sampler", rt.SAMPLER_BLUE))
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    osc = orc.OracleScene(hs.desc, 1)
+    p = rt.default_params(W, H, spp, **kw)
+    gp, gt = ds.primary_hits(hs.camera, p)
+    cp, ct = osc.primary_hits(hs.camera, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    ga, _ = ds.render(hs.camera, p)
+    ca, _ = osc.render(hs.camera, p)
+    assert_radiance_close(ga, ca)
+    ds.close()
+
+
+def test_resolve_matches_and_keeps_reference_quirks(rt, orc, gpu_ctx):
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(40, 40, 4)
+    acc, _ = ds.render(hs.camera, p)
+    raw, u8 = rt.resolve(acc, 4)
+    oraw, ou8 = orc.resolve(acc, 4)
+    assert np.array_equal(raw, oraw) and np.array_equal(u8, ou8)
+    assert raw.max() > 255  # the light saturates: (255.99*c) as i32 is not clamped (src/bin/main.rs:48-50)
+    ds.close()
+
+
+def test_accumulates_across_calls_and_sample_ranges_add_up(rt, gpu_ctx):
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    whole, _ = ds.render(hs.camera, rt.default_params(40, 40, 8))
+    acc = None
+    for b, e in ((0, 3), (3, 3), (3, 8)):  # an empty range in the middle changes nothing
+        acc, st = ds.render(hs.camera, rt.default_params(40, 40, 8, spp_begin=b, spp_end=e), acc)
+        assert st.camera_samples == 40 * 40 * (e - b)
+    assert_radiance_close(acc, whole, rel=1e-5)
+    ds.close()
+
+
+def test_tile_shards_compose_to_the_whole_frame(rt, gpu_ctx):
+    W, H = 75, 50
+    hs = rt.HostScene("utah", W / H)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    whole, st = ds.render(hs.camera, rt.default_params(W, H, 2))
+    prim, _ = ds.primary_hits(hs.camera, rt.default_params(W, H, 2))
+    acc = None
+    cams = 0
+    union = np.full((H, W), -2, np.int32)
+    for r in range(3):
+        p = rt.plan_shards("tile", r, 3, 2, tile_size=16).apply(rt.default_params(W, H, 2))
+        acc, s = ds.render(hs.camera, p, acc)
+        cams += s.camera_samples
+        pr, _ = ds.primary_hits(hs.camera, p)
+        ys, xs = np.mgrid[0:H, 0:W]
+        mine = ((ys // 16) * ((W + 15) // 16) + xs // 16) % 3 == r
+        assert (pr[~mine] == -1).all()
+        union[mine] = pr[mine]
+    assert cams == st.camera_samples == W * H * 2
+    assert np.array_equal(union, prim)
+    assert_radiance_close(acc, whole, rel=1e-5)
+    ds.close()
+
+
+def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, monkeypatch):
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(96, 96, 8)
+    big, st_big = ds.render(hs.camera, p)
+    monkeypatch.setenv("RT_QUEUE_TARGET", "16384")
+    small, st_small = ds.render(hs.camera, p)
+    assert st_small.iterations > st_big.iterations
+    assert (st_small.rays_closest, st_small.rays_shadow, st_small.camera_samples) == (st_big.rays_closest, st_big.rays_shadow, st_big.camera_samples)
+    assert_radiance_close(small, big, rel=1e-5)
+    ds.close()
+
+
+def test_light_spectrum_is_linear(rt, gpu_ctx):
+    hs = rt.HostScene("head", 1.0)
+    d = hs.desc
+    ds = rt.DeviceScene(gpu_ctx, d)
+    p = rt.default_params(48, 48, 4)
+    a, _ = ds.render(hs.camera, p)
+    for k in range(3):
+        d.lights[0].spectrum[k] *= 2.0
+    ds2 = rt.DeviceScene(gpu_ctx, d)
+    b, _ = ds2.render(hs.camera, p)
+    assert_radiance_close(b, 2.0 * a, rel=1e-5)
+    ds.close()
+    ds2.close()
+
+
+# ---- edge cases ---------------------------------------------------------------------------------------------------
+def test_empty_world_is_black_and_traces_only_primary_rays(rt, orc, gpu_ctx):
+    sc = rt.NumpyScene()
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    p = rt.default_params(16, 16, 2)
+    acc, st = ds.render(cam, p)
+    assert not acc.any() and st.rays_closest == 16 * 16 * 2 and st.rays_shadow == 0
+    prim, t = ds.primary_hits(cam, p)
+    assert (prim == -1).all() and not t.any()
+    ds.close()
+
+
+def test_light_only_world(rt, orc, gpu_ctx):
+    light = rt.Light(rt.LIGHT_DISK, (0, 0, -3), 0.0, (2, 3, 4), 0, 0, 1)
+    light.radius = 50.0  # a horizontal disk through the view axis is seen edge-on: never hit; tilt the camera instead
+    sc = rt.NumpyScene(lights=[light])
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    cam = rt.camera_new((0, 4, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    p = rt.default_params(24, 24, 2)
+    ga, _ = ds.render(cam, p)
+    ca, _ = orc.OracleScene(sc.desc, 0, sc).render(cam, p)
+    assert ca.any()
+    assert_radiance_close(ga, ca)
+    ds.close()
+
+
+def test_tie_backface_and_degenerate_triangles(rt, orc, gpu_ctx):
+    floor0 = [-1, -1, -1, 1, -1, -1, 1, -1, -3]
+    floor1 = [-1, -1, -1, 1, -1, -3, -1, -1, -3]
+    degenerate = [0, 0, -2, 0, 0, -2, 1, 1, -2]  # zero area: det == 0 -> never hit (src/geometry.rs:38-40)
+    back = [-1, 1, -3, 1, 1, -3, 1, -1, -3]      # back wall facing away from the camera: culled
+    dup = list(floor0)                           # an exact duplicate later in the list wins every tie
+    sc = rt.NumpyScene(tri_v=[floor0, floor1, degenerate, back, dup], tri_mat=[0] * 5, mats=[rt.diffuse(0.8, 0.8, 0.8)],
+                       lights=[rt.Light(rt.LIGHT_POINT, (0, 0.5, -2), 0, (3, 3, 3), 0, 0, 1)])
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    osc = orc.OracleScene(sc.desc, 0, sc)
+    cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    for sampler in (rt.SAMPLER_UNIFORM, rt.SAMPLER_WHITE):
+        p = rt.default_params(64, 64, 1, pixel_sampler=sampler)
+        gp, gt = ds.primary_hits(cam, p)
+        cp, ct = osc.primary_hits(cam, p)
+        assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+        assert set(np.unique(gp)) <= {-1, 1, 4}  # floor0 always loses to its duplicate, the back face and the sliver never appear
+        ga, _ = ds.render(cam, p)
+        ca, _ = osc.render(cam, p)
+        assert_radiance_close(ga, ca)
+    ds.close()
+
+
+def test_axis_aligned_cube_is_intact(rt, orc, gpu_ctx):
+    """cube.obj has only axis-aligned faces: their boxes are flat.  The reference's BVH can never hit a flat box
+    (src/mesh.rs:117); here every mesh returns the brute-force result, so all faces the camera sees are hit."""
+    cube = rt.load_obj(os.path.join(rt.ASSET_DIR, "cube.obj")) * np.float32(0.2) + np.tile(np.array([-0.5, -0.5, -3.0], np.float32), 3)
+    sc = rt.NumpyScene(tri_v=cube, tri_mat=[0] * 12, mats=[rt.diffuse(0.8, 0.8, 0.8)], objects=[rt.Object(rt.OBJ_MESH, 0, 12, 2)],
+                       lights=[rt.Light(rt.LIGHT_POINT, (2, 2, 0), 0, (9, 9, 9), 0, 0, 1)])
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    cam = rt.camera_new((1.5, 1.2, 2), (0, 0, -2.5), (0, 1, 0), 90.0, 1.0)
+    p = rt.default_params(96, 96, 1)
+    gp, gt = ds.primary_hits(cam, p)
+    cp, ct = orc.OracleScene(sc.desc, 0, sc).primary_hits(cam, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    assert len(set(np.unique(gp)) - {-1}) >= 4  # at least two visible faces, both triangles of each
+    ds.close()
+
+
+# ---- error behaviour ----------------------------------------------------------------------------------------------
+def test_unsupported_shader_combinations(rt, gpu_ctx):
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    for shader in (rt.SHADER_WHITTED, rt.SHADER_PATH):
+        with pytest.raises(rt.RtError) as e:
+            ds.render(hs.camera, rt.default_params(8, 8, 1, shader=shader))
+        assert e.value.code == rt.RT_ERR_UNSUPPORTED
+    ds.close()
+
+
+@pytest.mark.parametrize("kw,msg", [({"pixel_sampler": 0}, "unexpected integer"), ({"spp_end": 99}, "sample range"), ({"shader": 7}, "bad shader"),
+                                    ({"tile_size": 8, "shard_count": 0}, "tile sharding"), ({"max_depth": 100}, "max_depth")])
+def test_bad_params(rt, gpu_ctx, kw, msg):
+    hs = rt.HostScene("light_test", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    with pytest.raises(rt.RtError, match=msg) as e:
+        ds.render(hs.camera, rt.default_params(8, 8, 4, **kw))
+    assert e.value.code == rt.RT_ERR_INVALID
+    ds.close()
+
+
+def test_bad_scenes(rt, gpu_ctx):
+    tri = [[0, 0, 0, 1, 0, 0, 0, 1, 0]]
+    with pytest.raises(rt.RtError, match="no material"):  # panic!("no material"), src/shader.rs:46
+        sc = rt.NumpyScene(tri_v=tri, tri_mat=[3], mats=[rt.diffuse(1, 1, 1)])
+        rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    with pytest.raises(rt.RtError, match="world order"):
+        sc = rt.NumpyScene(tri_v=tri * 2, tri_mat=[0, 0], mats=[rt.diffuse(1, 1, 1)], objects=[rt.Object(rt.OBJ_TRIANGLE, 1, 1, 0), rt.Object(rt.OBJ_TRIANGLE, 0, 1, 0)])
+        rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    with pytest.raises(rt.RtError, match="not 2D"):  # src/light.rs:258-261
+        sc = rt.NumpyScene(lights=[rt.Light(rt.LIGHT_POLYGON, (0, 0, 0), 0, (1, 1, 1), 0, 2, 1)],
+                           light_tri_v=[[0, 0, 0, 1, 0, 0, 0, 0, 1], [0, 0, 0, 0, 1, 0, 1, 0, 0]])
+        rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    with pytest.raises(rt.RtError, match="unexpected integer"):
+        sc = rt.NumpyScene(lights=[rt.Light(rt.LIGHT_DISK, (0, 1, 0), 0.4, (1, 1, 1), 0, 0, 9)])
+        rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    lib = rt.hip_lib()
+    assert lib.rt_render(None, None, None, None, 0, None) == rt.RT_ERR_INVALID
+    bad = C.c_void_p()
+    assert lib.rt_context_create(4096, C.byref(bad)) == rt.RT_ERR_INVALID and b"no such device" in lib.rt_last_error()
+
+
+# ---- full-size properties -----------------------------------------------------------------------------------------
+def test_full_size_primary_ids_utah_1080p(rt, orc, gpu_ctx):
+    W, H = 1920, 1080
+    hs = rt.HostScene("utah", W / H)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(W, H, 256, seed=1)
+    gp, gt = ds.primary_hits(hs.camera, p)
+    cp, ct = orc.OracleScene(hs.desc, 1).primary_hits(hs.camera, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    assert (gp >= 0).mean() > 0.5
+    ds.close()
+
+
+def test_full_size_render_properties_miku_1080p(rt, gpu_ctx):
+    """At the benchmark frame size the oracle is too slow for a full comparison; these hold for any correct render:
+    ray counts are a pure function of the inputs, sample ranges add up, nothing is NaN or negative, and a pixel that
+    looks straight into the light holds exactly spp * spectrum (src/shader.rs:108-110)."""
+    torch = pytest.importorskip("torch")
+    W, H = 1920, 1080
+    hs = rt.HostScene("miku", W / H)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    dev = torch.device("cuda", 0)
+    a = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    b = torch.zeros_like(a)
+    torch.cuda.synchronize()
+    s_all = ds.render_device(hs.camera, rt.default_params(W, H, 1024, spp_begin=0, spp_end=2), a.data_ptr())
+    s0 = ds.render_device(hs.camera, rt.default_params(W, H, 1024, spp_begin=0, spp_end=1), b.data_ptr())
+    s1 = ds.render_device(hs.camera, rt.default_params(W, H, 1024, spp_begin=1, spp_end=2), b.data_ptr())
+    assert s_all.camera_samples == 2 * W * H
+    assert s_all.rays_closest == s0.rays_closest + s1.rays_closest and s_all.rays_shadow == s0.rays_shadow + s1.rays_shadow
+    assert torch.isfinite(a).all()
+    err = ((a - b).abs() / a.abs().clamp_min(FLOOR)).max().item()
+    assert err <= 1e-5
+    assert a.min().item() >= 0.0 and a.max().item() > 0.0
+    # the ceiling light (x in [-0.22, 0.22], y = 1, z in [-2.22, -1.78]) projects onto the frame around u = 0.5, v = 0.86
+    spectrum = torch.tensor(list(hs.desc.lights[0].spectrum), device=dev)
+    px = a[int((1 - 0.875) * H), W // 2]
+    assert torch.equal(px, 2 * spectrum), px
+    # device resolve == host resolve
+    rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    assert rt.hip_lib().rt_resolve_device(gpu_ctx._h, a.data_ptr(), W * H, 2, rgb.data_ptr()) == 0
+    _, u8 = rt.resolve(a.cpu().numpy(), 2)
+    assert np.array_equal(rgb.cpu().numpy(), u8)
+    ds.close()

@@ -1,0 +1,132 @@
+"""Host scene library (include/rt_host.h): the mirror of the reference's Scene/Mesh/Camera/obj_loader API."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+
+def test_head_scene_layout(rt):
+    hs = rt.HostScene("head", 1.0)
+    d = hs.desc
+    # src/scene.rs:170-351: 10 wall triangles, 9 Microfacet spheres, one two-triangle polygon light
+    assert (d.n_tri, d.n_sph, d.n_cyl, d.n_light, d.n_light_tri, d.n_obj) == (10, 9, 0, 1, 2, 19)
+    kinds = [d.objects[i].kind for i in range(d.n_obj)]
+    assert kinds == [rt.OBJ_TRIANGLE] * 10 + [rt.OBJ_SPHERE] * 9
+    mats = [d.mats[i] for i in range(d.n_mat)]
+    assert sum(m.kind == rt.MAT_DIFFUSE for m in mats) == 3 and sum(m.kind == rt.MAT_MICROFACET for m in mats) == 9
+    sph = np.ctypeslib.as_array(d.sph, shape=(9, 4))
+    assert np.allclose(sph[0], [-0.6, -0.75, -2.5, 0.25]) and np.allclose(sph[8], [0.6, 0.5, -2.5, 0.25])
+    light = d.lights[0]
+    assert light.kind == rt.LIGHT_POLYGON and np.allclose(list(light.spectrum), np.array([0.9, 0.64, 0.28]) * 22.0)
+    tri = np.ctypeslib.as_array(d.tri_v, shape=(10, 9))
+    assert np.allclose(tri[0], [-1, -1, -1, 1, -1, -1, 1, -1, -3]) and np.allclose(tri[1], [-1, -1, -1, 1, -1, -3, -1, -1, -3])
+
+
+@pytest.mark.parametrize("name,ntri,nsph,ncyl,nlight", [("blue_noise_test", 24 * 24 * 2, 0, 0, 1), ("light_test", 2, 0, 0, 3), ("mis_test", 12, 0, 0, 4),
+                                                        ("utah", 6320 + 10, 0, 0, 1), ("miku", 30885 + 10, 0, 0, 1), ("whitted", 12 + 4 + 10, 2, 1, 1),
+                                                        ("cornell", 6320 + 2 * 30885 + 4 + 10, 1, 1, 1), ("composite", 6320 + 2 * 30885 + 4 + 10, 1, 1, 1)])
+def test_catalogue_counts(rt, name, ntri, nsph, ncyl, nlight):
+    hs = rt.HostScene(name, 1.0)  # keeps the arrays behind desc alive
+    d = hs.desc
+    assert (d.n_tri, d.n_sph, d.n_cyl, d.n_light) == (ntri, nsph, ncyl, nlight)
+    # objects cover the class arrays in world order
+    nt = ns = nc = 0
+    for i in range(d.n_obj):
+        o = d.objects[i]
+        if o.kind in (rt.OBJ_TRIANGLE, rt.OBJ_MESH):
+            assert o.first == nt
+            nt += o.count
+        elif o.kind == rt.OBJ_SPHERE:
+            assert o.first == ns
+            ns += 1
+        else:
+            assert o.first == nc
+            nc += 1
+    assert (nt, ns, nc) == (ntri, nsph, ncyl)
+
+
+def test_unknown_scene_and_sampler_are_errors(rt):
+    with pytest.raises(rt.RtError, match="unknown scene"):
+        rt.HostScene("nope", 1.0)
+    with pytest.raises(rt.RtError, match="unexpected integer"):  # SamplerKind::from_int, src/sampler.rs:13-21
+        rt.HostScene("head", 1.0, light_sampler=5)
+    with pytest.raises(rt.RtError, match="cannot open"):
+        rt.HostScene("utah", 1.0, asset_dir="/nonexistent")
+
+
+def test_camera_matches_oracle(rt, orc):
+    for args in [((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0), ((0, 1.5, 3), (0, 0, -1), (0, 1, 0), 90.0, 16 / 9), ((1, 2, 3), (-1, 0.5, -4), (0.1, 1, 0), 37.5, 1.25)]:
+        a, b = rt.camera_new(*args), orc.camera_new(*args)
+        assert bytes(a) == bytes(b)
+    cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    # the reference's lower_left_corner is the constant (-hw, -hh, -1), not offset by the origin (src/camera.rs:23)
+    assert np.allclose(list(cam.llc), [-1, -1, -1]) and np.allclose(list(cam.horizontal), [2, 0, 0]) and np.allclose(list(cam.vertical), [0, 2, 0])
+
+
+def test_obj_loader(rt, tmp_path):
+    cube = rt.load_obj(os.path.join(rt.ASSET_DIR, "cube.obj"))
+    assert cube.shape == (12, 9)
+    assert np.array_equal(cube[0], [0, 0, 0, 5, 5, 0, 5, 0, 0])  # f 1//2 7//2 5//2
+    p = tmp_path / "quad.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    with pytest.raises(rt.RtError, match="triangulated"):  # obj-rs refuses polygons for load_obj::<Position>
+        rt.load_obj(str(p))
+    p2 = tmp_path / "rel.obj"
+    p2.write_text("# comment\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf -3/1/1 -2/1/1 -1/1/1\n")
+    assert np.array_equal(rt.load_obj(str(p2))[0], [0, 0, 0, 1, 0, 0, 0, 1, 0])
+    p3 = tmp_path / "bad.obj"
+    p3.write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(rt.RtError, match="out of range"):
+        rt.load_obj(str(p3))
+
+
+def test_mesh_transform(rt):
+    pts = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    # scale then rotate about the origin then displace (src/mesh.rs:23-39)
+    out = rt.transform_points(pts, 2.0, (1, 2, 3), 0, 0, 0)
+    assert np.allclose(out, pts * 2 + [1, 2, 3])
+    # x = -90 deg turns a z-up model y-up: z -> y, y -> -z
+    out = rt.transform_points(pts, 1.0, (0, 0, 0), -90, 0, 0)
+    assert np.allclose(out, [[1, 0, 0], [0, 0, -1], [0, 1, 0]], atol=1e-6)
+    # R = Rx * Ry * Rz: z rotation is applied first
+    out = rt.transform_points(np.array([[1, 0, 0]], np.float32), 1.0, (0, 0, 0), 90, 0, 90)
+    assert np.allclose(out, [[0, 0, 1]], atol=1e-6)
+    c, s = math.cos(math.radians(-15)), math.sin(math.radians(-15))
+    out = rt.transform_points(np.array([[1, 0, 0]], np.float32), 1.0, (0, 0, 0), 0, -15, 0)
+    assert np.allclose(out, [[c, 0, -s]], atol=1e-6)
+
+
+def test_miku_is_upright_in_the_bench_scene(rt):
+    hs = rt.HostScene("miku", 1.0)
+    d = hs.desc
+    tri = np.ctypeslib.as_array(d.tri_v, shape=(d.n_tri, 9))[:30885].reshape(-1, 3)
+    ext = tri.max(0) - tri.min(0)
+    assert ext[1] > ext[0] and ext[1] > ext[2]  # tallest along y
+    assert abs(tri[:, 1].min() - (-1.0)) < 0.05  # feet on the floor
+
+
+def test_write_ppm(rt, tmp_path):
+    img = np.arange(2 * 3 * 3, dtype=np.int32).reshape(2, 3, 3) * 20
+    path = tmp_path / "o.ppm"
+    rt.write_ppm(str(path), img)
+    lines = path.read_text().split("\n")
+    assert lines[:3] == ["P3", "3 2", "255"]  # src/bin/main.rs:27
+    assert lines[3] == "0 20 40" and lines[8] == "300 320 340"  # raw integers, no clamp (main.rs:48-51)
+
+
+def test_sharding_plans(rt):
+    plans = [rt.plan_shards("spp", r, 8, 4096) for r in range(8)]
+    assert [(p.spp_begin, p.spp_end) for p in plans] == [(512 * r, 512 * (r + 1)) for r in range(8)]
+    plans = [rt.plan_shards("spp", r, 3, 16) for r in range(3)]
+    assert plans[0].spp_begin == 0 and plans[-1].spp_end == 16
+    assert all(a.spp_end == b.spp_begin for a, b in zip(plans, plans[1:]))
+    t = rt.plan_shards("tile", 3, 8, 1024, tile_size=64)
+    p = t.apply(rt.default_params(1920, 1080, 1024))
+    assert (p.tile_size, p.shard_rank, p.shard_count, p.spp_begin, p.spp_end) == (64, 3, 8, 0, 1024)
+    assert rt.plan_shards("tile", 0, 1, 16).tile_size == 0
+    with pytest.raises(ValueError):
+        rt.plan_shards("rows", 0, 1, 16)
+    with pytest.raises(ValueError):
+        rt.plan_shards("spp", 2, 2, 16)

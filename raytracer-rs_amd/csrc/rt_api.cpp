@@ -54,6 +54,13 @@ template <class T> struct DevBuf {
     }
 };
 
+uint32_t env_u32_allow_zero(const char *name, uint32_t dflt) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    long long x = std::atoll(v);
+    return x >= 0 ? (uint32_t)x : dflt;
+}
+
 uint32_t env_u32(const char *name, uint32_t dflt) {
     const char *v = std::getenv(name);
     if (!v || !*v) return dflt;
@@ -362,7 +369,7 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     } while (0)
 
     BvhBuild bvh;
-    const int max_top = (int)env_u32("RT_BVH_TOP", 512);
+    const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 128);
     build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, &bvh);
     UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
     UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
@@ -383,6 +390,36 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     s->dev.cyl = s->cyl.p; s->dev.cyl_info = s->cyl_info.p; s->dev.mats = s->mats.p; s->dev.lights = s->lights.p; s->dev.ltris = s->ltris.p;
     s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
     s->dev.n_light = d->n_light;
+    // boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box)
+    {
+        struct MB { int count; float mn[3], mx[3]; };
+        std::vector<MB> mbs;
+        for (int i = 0; i < d->n_obj; i++) {
+            const rt_object &ob = d->objects[i];
+            if (ob.kind != RT_OBJ_MESH || ob.count < 64) continue;
+            MB mb{ob.count, {1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
+            for (int f = 0; f < ob.count * 3; f++) {
+                const float *v = d->tri_v + 9 * (size_t)ob.first + 3 * (size_t)f;
+                for (int a = 0; a < 3; a++) { mb.mn[a] = std::min(mb.mn[a], v[a]); mb.mx[a] = std::max(mb.mx[a], v[a]); }
+            }
+            mbs.push_back(mb);
+        }
+        std::sort(mbs.begin(), mbs.end(), [](const MB &a, const MB &b) { return a.count > b.count; });
+        s->dev.n_heavy = 0;
+        for (size_t i = 0; i < mbs.size(); i++) {
+            int k = (int)std::min<size_t>(i, RT_MAX_HEAVY - 1);
+            if ((int)i < RT_MAX_HEAVY) {
+                for (int a = 0; a < 3; a++) { s->dev.heavy_min[k][a] = mbs[i].mn[a]; s->dev.heavy_max[k][a] = mbs[i].mx[a]; }
+                s->dev.n_heavy = k + 1;
+            } else {
+                for (int a = 0; a < 3; a++) {
+                    s->dev.heavy_min[k][a] = std::min(s->dev.heavy_min[k][a], mbs[i].mn[a]);
+                    s->dev.heavy_max[k][a] = std::max(s->dev.heavy_max[k][a], mbs[i].mx[a]);
+                }
+            }
+        }
+        if (env_u32("RT_NO_HEAVY", 0)) s->dev.n_heavy = 0;
+    }
     for (const DevLight &L : lights) { s->n_disk_lights += L.kind == RT_LIGHT_DISK; s->n_point_lights += L.kind == RT_LIGHT_POINT; }
     *out = s;
     return RT_OK;
@@ -437,9 +474,8 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
 
-    // queue geometry: RT_NSEG segments per queue; a queue holds 4x the refill level so that bursts of branching
-    // (Microfacet spawns two rays per hit) fit; running out of room is reported, never silent
-    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 21);
+    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`
+    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 23);
     // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
     // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
     uint32_t per_node = 1;
@@ -447,8 +483,10 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     if (per_node > 1) target = std::max<uint32_t>(1u << 16, target / 8);
     if (total < target) target = (uint32_t)total;
     target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
-    const uint32_t seg_capacity = 4u * target / RT_NSEG;
-    const uint32_t shadow_seg_capacity = (per_node > 1 ? 2u * target / RT_NSEG * per_node : seg_capacity);
+    // a segment holds 8x its even share of the refill level: bursts of branching (Microfacet spawns two rays per hit)
+    // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
+    const uint32_t seg_capacity = 8u * (target / RT_NSEG);
+    const uint32_t shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
     rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, n_pixels);
     if (rc) return rc;
 
@@ -488,13 +526,13 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
             if (c.n_new) {
                 timer.begin(3);
-                launch_raygen(cfg, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
+                launch_raygen(cfg, s->dev, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
                 timer.end();
                 st.launches_raygen++;
             }
             // most nodes any segment can hold after ray generation: what it carried in + its share of the raygen workgroups
             const uint32_t new_blocks = (c.n_new + 255u) / 256u;
-            const uint32_t seg_threads = std::min(seg_capacity, c.max_in + ((new_blocks + RT_NSEG - 1) / RT_NSEG) * 256u);
+            const uint32_t seg_threads = std::min(seg_capacity, c.max_in + ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * 256u);
             timer.begin(0);
             launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, seg_threads, count_work);
             timer.end();
@@ -504,10 +542,10 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             timer.end();
             st.launches_shade++;
             if (p->shader != RT_SHADER_PATH) {
-                // shade workgroup (bx, s) appends to segment (bx + s) % RT_NSEG: a segment receives from at most
-                // ceil(blocks_x) * 1 workgroups per source segment, i.e. blocks_x * RT_NSEG / RT_NSEG * 256 * per_node rays
+                // shade workgroup (bx, s) appends to segments (bx + s) % RT_NSEG_HALF (+ RT_NSEG_HALF for heavy rays): for every
+                // bx exactly two source segments map onto a given target, so it receives from 2 * blocks_x workgroups
                 const uint32_t bx = (seg_threads + 255u) / 256u;
-                const unsigned long long bound = (unsigned long long)bx * 256ull * per_node;
+                const unsigned long long bound = 2ull * bx * 256ull * per_node;
                 timer.begin(2);
                 launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels,
                               (uint32_t)std::min<unsigned long long>(bound, shadow_seg_capacity), count_work);

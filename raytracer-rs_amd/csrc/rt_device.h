@@ -115,7 +115,29 @@ struct DevScene {
     const DevLight *lights;
     const float *ltris;     // 9 floats per light triangle
     int32_t n_nodes, n_top, n_tri, n_sph, n_cyl, n_light;
+    // Boxes around the big meshes.  A ray that touches one is expected to walk deep into the BVH ("heavy"), the others
+    // only meet the few large triangles around them; the queues keep the two kinds apart so that the lanes of a wave
+    // have similar trip counts.  Purely a scheduling hint: results do not depend on it.
+    int32_t n_heavy;
+    float heavy_min[4][3];
+    float heavy_max[4][3];
 };
+
+#define RT_MAX_HEAVY 4
+
+__device__ __forceinline__ bool ray_is_heavy(const DevScene &sc, F3 o, F3 d, float t_min, float t_max) {
+    bool heavy = false;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    for (int k = 0; k < sc.n_heavy; k++) {
+        float x0 = (sc.heavy_min[k][0] - o.x) * ix, x1 = (sc.heavy_max[k][0] - o.x) * ix;
+        float y0 = (sc.heavy_min[k][1] - o.y) * iy, y1 = (sc.heavy_max[k][1] - o.y) * iy;
+        float z0 = (sc.heavy_min[k][2] - o.z) * iz, z1 = (sc.heavy_max[k][2] - o.z) * iz;
+        float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+        float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+        heavy |= tn <= tf;
+    }
+    return heavy;
+}
 
 struct RenderConst {
     rt_camera cam;
@@ -219,65 +241,77 @@ struct TriHit {
     int prim; // primitive id
 };
 
-template <bool ANY_HIT, bool COUNT>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte fetches through buffer descriptors: one instruction per node half / triangle third that the compiler can
+// neither split nor sink below the box test (a plain float4 load had its .w lane re-fetched after the test: one more
+// dependent memory round trip per visited node), 32-bit offsets, and out-of-range reads return zero instead of faulting.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_offset, 0, 0);
+}
+__device__ __forceinline__ float u2f(unsigned int v) { return __uint_as_float(v); }
+
+template <bool ANY_HIT, bool COUNT, bool USE_LDS = false>
 __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     TriHit best{t_max, -1, -1};
     if (sc.n_nodes == 0) return best;
+    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * 32u);
+    const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     int node = 0;
     while (node >= 0) {
-        float4 na, nb;
-        if (node < sc.n_top) {
-            na = lds_nodes[2 * node];
-            nb = lds_nodes[2 * node + 1];
+        u32x4 na, nb;
+        if (USE_LDS && node < sc.n_top) {
+            const float4 fa = lds_nodes[2 * node], fb = lds_nodes[2 * node + 1];
+            na = u32x4{__float_as_uint(fa.x), __float_as_uint(fa.y), __float_as_uint(fa.z), __float_as_uint(fa.w)};
+            nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fb.z), __float_as_uint(fb.w)};
         } else {
-            na = sc.nodes[2 * node];
-            nb = sc.nodes[2 * node + 1];
+            na = load16(node_r, (uint32_t)node * 32u);
+            nb = load16(node_r, (uint32_t)node * 32u + 16u);
         }
         if (COUNT) (*n_nodes)++;
-        float x0 = (na.x - o.x) * ix, x1 = (nb.x - o.x) * ix;
-        float y0 = (na.y - o.y) * iy, y1 = (nb.y - o.y) * iy;
-        float z0 = (na.z - o.z) * iz, z1 = (nb.z - o.z) * iz;
-        float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
-        float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
-        int next = __float_as_int(nb.w);
-        if (tn <= tf * 1.00001f + 1e-7f) {
-            int link = __float_as_int(na.w);
-            if (link >= 0) {
-                next = link;
-            } else {
-                int packed = ~link;
-                int first = packed >> 3, count = (packed & 7) + 1;
-                for (int k = 0; k < count; k++) {
-                    const float4 *tp = sc.tris + 3 * (first + k);
-                    float4 a = tp[0], b = tp[1], c = tp[2];
-                    if (COUNT) (*n_tris)++;
-                    float t;
-                    if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
-                        int prim = __float_as_int(a.w);
-                        if (ANY_HIT) {
-                            best.t = t; best.tri = first + k; best.prim = prim;
-                            return best;
-                        }
-                        if (t < best.t || (t == best.t && prim > best.prim)) {
-                            best.t = t; best.tri = first + k; best.prim = prim;
-                        }
+        const float x0 = (u2f(na.x) - o.x) * ix, x1 = (u2f(nb.x) - o.x) * ix;
+        const float y0 = (u2f(na.y) - o.y) * iy, y1 = (u2f(nb.y) - o.y) * iy;
+        const float z0 = (u2f(na.z) - o.z) * iz, z1 = (u2f(nb.z) - o.z) * iz;
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
+        const bool inside = tn <= tf * 1.00001f + 1e-7f;
+        const int link = (int)na.w, miss = (int)nb.w;
+        node = (inside && link >= 0) ? link : miss;
+        if (inside && link < 0) {
+            const int packed = ~link;
+            const int first = packed >> 3, count = (packed & 7) + 1;
+            for (int k = 0; k < count; k++) {
+                const uint32_t off = (uint32_t)(first + k) * 48u;
+                const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
+                if (COUNT) (*n_tris)++;
+                float t;
+                if (tri_hit(f3(u2f(a.x), u2f(a.y), u2f(a.z)), f3(u2f(b.x), u2f(b.y), u2f(b.z)), f3(u2f(c.x), u2f(c.y), u2f(c.z)), o, d, t_min, t_max, false, &t)) {
+                    const int prim = (int)a.w;
+                    if (ANY_HIT) {
+                        best.t = t; best.tri = first + k; best.prim = prim;
+                        return best;
+                    }
+                    if (t < best.t || (t == best.t && prim > best.prim)) {
+                        best.t = t; best.tri = first + k; best.prim = prim;
                     }
                 }
             }
         }
-        node = next;
     }
     return best;
 }
 
 // world.objects.hit (hitable.rs:35-62): triangles through the BVH, then spheres and cylinders in order.  A sphere or
 // cylinder needs t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.
-template <bool COUNT>
+template <bool COUNT, bool USE_LDS = false>
 __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max, float *t_out,
                                           int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
-    TriHit th = bvh_traverse<false, COUNT>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    TriHit th = bvh_traverse<false, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
     float closest = th.t;
     int code = th.tri >= 0 ? hit_code(HIT_KIND_TRI, th.tri) : HIT_NONE;
     int prim = th.prim;
@@ -296,7 +330,7 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)
-template <bool COUNT>
+template <bool COUNT, bool USE_LDS = false>
 __device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     for (int i = 0; i < sc.n_sph; i++) {
@@ -308,7 +342,7 @@ __device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 
         int kind;
         if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind)) return true;
     }
-    TriHit th = bvh_traverse<true, COUNT>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    TriHit th = bvh_traverse<true, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
     return th.tri >= 0;
 }
 

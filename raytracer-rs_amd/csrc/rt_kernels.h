@@ -26,8 +26,10 @@ struct ShadowQueue {
 
 // The queues are cut into NSEG equal segments, each with its own fill counter on its own 128-byte line: appends are
 // one returning atomic per workgroup, and a single counter word would serialise them (about 90 per microsecond).
-// Workgroup b of a producing kernel appends to segment b % NSEG; consumers run a (blocks, NSEG) grid.
+// Segments [0, RT_NSEG/2) hold "light" rays, [RT_NSEG/2, RT_NSEG) "heavy" ones (see DevScene::n_heavy); a producing
+// workgroup b appends to segment (b % (RT_NSEG/2)) of each half; consumers run a (blocks, NSEG) grid, heavy half first.
 #define RT_NSEG 32
+#define RT_NSEG_HALF (RT_NSEG / 2)
 
 struct SegCounter {
     uint32_t v;
@@ -68,7 +70,8 @@ struct LaunchCfg {
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl);
 // seg_threads = upper bound of the elements in any one segment (the grid is ceil(seg_threads/256) x RT_NSEG)
-void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w, uint32_t n_threads);
+void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
+                   uint32_t n_threads);
 void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads,
                    bool count);
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out,

@@ -12,6 +12,7 @@
 // Built with -ffp-contract=off: see rt_device.h.
 
 #include "rt_kernels.h"
+#include "rt_trace.h"
 
 namespace rtd {
 
@@ -35,37 +36,41 @@ __device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter) {
     return base + below;
 }
 
+// Six element streams in four groups, one counter per group (a group's streams share one reservation, laid out wave by
+// wave, stream by stream):  group 0 = {0,1} light children   group 1 = {2,3} heavy children
+//                           group 2 = {4}   light shadow ray  group 3 = {5}   heavy shadow ray
 struct BlockAppend {
-    uint32_t wave_cnt[BLOCK / 64][3];
-    uint32_t base[2];
+    uint32_t wave_cnt[BLOCK / 64][6];
+    uint32_t base[4];
 };
 
-// flags: a = first stream into counter A, b = second stream into counter A (placed after all of a), c = stream into counter B
-__device__ __forceinline__ void block_append3(BlockAppend &sm, bool a, bool b, bool c, uint32_t *counter_a, uint32_t *counter_b, uint32_t *slot_a,
-                                              uint32_t *slot_b, uint32_t *slot_c) {
+__device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)[6], uint32_t *const (&counter)[4], uint32_t (&slot)[6]) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long ma = __ballot(a), mb = __ballot(b), mc = __ballot(c);
-    const uint32_t below_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
-    const uint32_t below_b = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
-    const uint32_t below_c = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, 0u));
-    if (lane == 0) {
-        sm.wave_cnt[wave][0] = (uint32_t)__popcll(ma);
-        sm.wave_cnt[wave][1] = (uint32_t)__popcll(mb);
-        sm.wave_cnt[wave][2] = (uint32_t)__popcll(mc);
+    uint32_t below[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const unsigned long long m = __ballot(flag[k]);
+        below[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (lane == 0) sm.wave_cnt[wave][k] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t ta = 0, tc = 0;
-        for (int w = 0; w < BLOCK / 64; w++) { ta += sm.wave_cnt[w][0] + sm.wave_cnt[w][1]; tc += sm.wave_cnt[w][2]; }
-        sm.base[0] = ta ? atomicAdd(counter_a, ta) : 0u;
-        sm.base[1] = tc ? atomicAdd(counter_b, tc) : 0u;
+    if (threadIdx.x < 4) {
+        const int g = (int)threadIdx.x;
+        const int k0 = g < 2 ? 2 * g : g + 2, k1 = g < 2 ? 2 * g + 1 : g + 2;
+        uint32_t total = 0;
+        for (int w = 0; w < BLOCK / 64; w++) total += sm.wave_cnt[w][k0] + (k1 != k0 ? sm.wave_cnt[w][k1] : 0u);
+        sm.base[g] = total ? atomicAdd(counter[g], total) : 0u;
     }
     __syncthreads();
-    uint32_t oa = sm.base[0], oc = sm.base[1];
-    for (uint32_t w = 0; w < wave; w++) { oa += sm.wave_cnt[w][0] + sm.wave_cnt[w][1]; oc += sm.wave_cnt[w][2]; }
-    *slot_a = oa + below_a;
-    *slot_b = oa + sm.wave_cnt[wave][0] + below_b;
-    *slot_c = oc + below_c;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int g = k < 4 ? k >> 1 : k - 2;
+        const int k0 = g < 2 ? 2 * g : g + 2, k1 = g < 2 ? 2 * g + 1 : g + 2;
+        uint32_t off = sm.base[g];
+        for (uint32_t w = 0; w < wave; w++) off += sm.wave_cnt[w][k0] + (k1 != k0 ? sm.wave_cnt[w][k1] : 0u);
+        if (k != k0) off += sm.wave_cnt[wave][k0];
+        slot[k] = off + below[k];
+    }
     __syncthreads(); // sm may be reused by the next call
 }
 
@@ -146,7 +151,7 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
 // ---- k_raygen -------------------------------------------------------------------------------------------------------
 // Camera candidates are numbered sample-major: candidate c -> sample c / per_sample, 8x8 pixel block
 // (c % per_sample) / 64, pixel c % 64 inside the block.  One wave = one 8x8 block of one sample.
-__global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
+__global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                                                   uint32_t seg_capacity) {
     __shared__ BlockAppend sm;
     const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
@@ -177,26 +182,32 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(RenderConst rc, Ctl *ctl, Node
             }
         }
     }
-    const uint32_t seg = blockIdx.x % RT_NSEG;
-    uint32_t slot, s1, s2;
-    block_append3(sm, valid, false, false, &ctl->seg_in[seg].v, &ctl->seg_in[seg].v, &slot, &s1, &s2);
+    const bool heavy = valid && ray_is_heavy(sc, n.o, n.d, rc.t_min, rc.t_max);
+    const uint32_t seg_l = blockIdx.x % RT_NSEG_HALF, seg_h = RT_NSEG_HALF + seg_l;
+    const bool flag[6] = {valid && !heavy, false, heavy, false, false, false};
+    uint32_t *const counter[4] = {&ctl->seg_in[seg_l].v, &ctl->seg_in[seg_h].v, &ctl->seg_in[seg_l].v, &ctl->seg_in[seg_h].v};
+    uint32_t slot[6];
+    block_append(sm, flag, counter, slot);
     if (valid) {
-        if (slot < seg_capacity) store_node(in, seg * seg_capacity + slot, n);
+        const uint32_t sl = heavy ? slot[2] : slot[0];
+        if (sl < seg_capacity) store_node(in, (heavy ? seg_h : seg_l) * seg_capacity + sl, n);
         else ctl->h.overflow = 1;
     }
 }
 
 // ---- k_extend -------------------------------------------------------------------------------------------------------
 // grid (blocks, RT_NSEG): workgroup (bx, s) handles nodes [bx*256, bx*256+256) of segment s.
-// hit record: (t_obj, object code, t_light, light index)
-template <bool COUNT>
+// hit record: (t_obj, object code, -, -)
+template <bool COUNT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t seg = blockIdx.y;
+    const uint32_t seg = RT_NSEG - 1u - blockIdx.y; // heavy segments first: their workgroups run longest
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     if (blockIdx.x * BLOCK >= n_seg) return;
-    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-    __syncthreads();
+    if (USE_LDS) {
+        for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+        __syncthreads();
+    }
     const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
     if (il >= n_seg) return;
     const uint32_t i = seg * seg_capacity + il;
@@ -205,14 +216,32 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     float t_obj;
     int code, prim;
     uint32_t nn = 0, nt = 0;
-    world_hit<COUNT>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
-    float t_light = 0.0f;
-    int li = lights_hit(sc, o, d, rc.t_min, rc.t_max, &t_light);
-    hit[i] = make_float4(t_obj, __int_as_float(code), t_light, __int_as_float(li));
+    world_hit<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    hit[i] = make_float4(t_obj, __int_as_float(code), 0.0f, 0.0f);
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
         atomicAdd(&ctl->h.tris, (unsigned long long)nt);
     }
+}
+
+// ---- persistent traversal kernels (rt_trace.h) -------------------------------------------------------------------
+template <bool COUNT, int REFILL, int LEAF_T>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity) {
+    extern __shared__ float4 lds_nodes[];
+    __shared__ int chunk_prefix[RT_NSEG + 1];
+    __shared__ uint32_t seg_count[RT_NSEG];
+    trace_persistent<false, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_in[0].v, seg_capacity, in.a, in.b, nullptr, hit, nullptr, 0u, lds_nodes,
+                                                   chunk_prefix, seg_count);
+}
+
+template <bool COUNT, int REFILL, int LEAF_T>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
+                                                              uint32_t shadow_seg_capacity) {
+    extern __shared__ float4 lds_nodes[];
+    __shared__ int chunk_prefix[RT_NSEG + 1];
+    __shared__ uint32_t seg_count[RT_NSEG];
+    trace_persistent<true, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_shadow[0].v, shadow_seg_capacity, sh.a, sh.b, sh.c, nullptr, planes, n_pixels,
+                                                  lds_nodes, chunk_prefix, seg_count);
 }
 
 // ---- surface point ---------------------------------------------------------------------------------------------------
@@ -308,11 +337,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     if (blockIdx.x * BLOCK >= n_seg) return;
     const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t i = seg * seg_capacity + il;
-    const uint32_t oseg = (blockIdx.x + seg) % RT_NSEG;
+    const uint32_t oseg_l = (blockIdx.x + seg) % RT_NSEG_HALF, oseg_h = RT_NSEG_HALF + oseg_l;
 
     bool have0 = false, have1 = false, have_s = false;
     Node c0, c1;
-    F3 s_o, s_d, s_c;
+    F3 s_o = f3(0.0f, 0.0f, 0.0f), s_d = f3(0.0f, 0.0f, 1.0f), s_c = f3(0.0f, 0.0f, 0.0f);
     uint32_t s_pixel = 0;
     // Whitted's LightList::visible needs several shadow rays per surface point; they are produced after the main body
     bool vis_pending = false;
@@ -322,8 +351,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     if (il < n_seg) {
         Node nd = load_node(in, i);
         const float4 h = hit[i];
-        const float t_obj = h.x, t_l = h.z;
-        const int code = __float_as_int(h.y), li = __float_as_int(h.w);
+        const float t_obj = h.x;
+        const int code = __float_as_int(h.y);
+        // world.lights.hit(r) (shader.rs:99): tested here, where every lane of the wave is busy, not in the traversal kernel
+        float t_l = 0.0f;
+        const int li = lights_hit(sc, nd.o, nd.d, rc.t_min, rc.t_max, &t_l);
         const uint32_t pixel = nd.meta & 0xFFFFFFu, depth = (nd.meta >> 24) & 63u, root = (nd.meta >> 30) & 1u;
 
         // weight of this node: MIS divides by (light pdf + BSDF pdf) of the ray that led here (material.rs:465-467)
@@ -422,11 +454,24 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
         }
     }
 
-    // ---- compaction: children into the next queue, shadow rays into the shadow queue
-    uint32_t slot0, slot1, slot_s;
-    block_append3(sm, have0, have1, SHADER != RT_SHADER_WHITTED && have_s, &ctl->seg_out[oseg].v, &ctl->seg_shadow[oseg].v, &slot0, &slot1, &slot_s);
-    if (have0) { if (slot0 < seg_capacity) store_node(out, oseg * seg_capacity + slot0, c0); else ctl->h.overflow = 1; }
-    if (have1) { if (slot1 < seg_capacity) store_node(out, oseg * seg_capacity + slot1, c1); else ctl->h.overflow = 1; }
+    // ---- compaction: children into the next queue, shadow rays into the shadow queue, light and heavy rays apart
+    const bool heavy0 = have0 && ray_is_heavy(sc, c0.o, c0.d, rc.t_min, rc.t_max);
+    const bool heavy1 = have1 && ray_is_heavy(sc, c1.o, c1.d, rc.t_min, rc.t_max);
+    const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
+    const bool heavy_s = nee && ray_is_heavy(sc, s_o, s_d, rc.t_min, 1.0f - rc.t_min);
+    const bool flag[6] = {have0 && !heavy0, have1 && !heavy1, heavy0, heavy1, nee && !heavy_s, heavy_s};
+    uint32_t *const counter[4] = {&ctl->seg_out[oseg_l].v, &ctl->seg_out[oseg_h].v, &ctl->seg_shadow[oseg_l].v, &ctl->seg_shadow[oseg_h].v};
+    uint32_t slot[6];
+    block_append(sm, flag, counter, slot);
+    if (have0) {
+        const uint32_t sl = heavy0 ? slot[2] : slot[0];
+        if (sl < seg_capacity) store_node(out, (heavy0 ? oseg_h : oseg_l) * seg_capacity + sl, c0); else ctl->h.overflow = 1;
+    }
+    if (have1) {
+        const uint32_t sl = heavy1 ? slot[3] : slot[1];
+        if (sl < seg_capacity) store_node(out, (heavy1 ? oseg_h : oseg_l) * seg_capacity + sl, c1); else ctl->h.overflow = 1;
+    }
+    const uint32_t oseg = oseg_l; // the Whitted multi-ray path below does not classify
 
     if (SHADER == RT_SHADER_WHITTED) {
         // LightList::visible (light.rs:368-385): every light; a disk light is sampled light_samples times (light.rs:150-181)
@@ -504,26 +549,29 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
         }
     } else {
         if (have_s) {
+            const uint32_t slot_s = heavy_s ? slot[5] : slot[4];
             if (slot_s < shadow_seg_capacity) {
-                const uint32_t slot = oseg * shadow_seg_capacity + slot_s;
-                sh.a[slot] = make_float4(s_o.x, s_o.y, s_o.z, s_d.x);
-                sh.b[slot] = make_float4(s_d.y, s_d.z, s_c.x, s_c.y);
-                sh.c[slot] = make_float2(s_c.z, __uint_as_float(s_pixel));
+                const uint32_t si = (heavy_s ? oseg_h : oseg_l) * shadow_seg_capacity + slot_s;
+                sh.a[si] = make_float4(s_o.x, s_o.y, s_o.z, s_d.x);
+                sh.b[si] = make_float4(s_d.y, s_d.z, s_c.x, s_c.y);
+                sh.c[si] = make_float2(s_c.z, __uint_as_float(s_pixel));
             } else ctl->h.overflow = 1;
         }
     }
 }
 
 // ---- k_shadow --------------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
                                                   uint32_t shadow_seg_capacity) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t seg = blockIdx.y;
+    const uint32_t seg = RT_NSEG - 1u - blockIdx.y;
     const uint32_t n = min(ctl->seg_shadow[seg].v, shadow_seg_capacity);
     if (blockIdx.x * BLOCK >= n) return;
-    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-    __syncthreads();
+    if (USE_LDS) {
+        for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
+        __syncthreads();
+    }
     const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
     if (il >= n) return;
     const uint32_t i = seg * shadow_seg_capacity + il;
@@ -531,7 +579,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     float2 c = sh.c[i];
     F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     uint32_t nn = 0, nt = 0;
-    bool occ = world_occluded<COUNT>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    bool occ = world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
@@ -620,16 +668,56 @@ static inline size_t lds_bytes(const DevScene &sc) { return (size_t)sc.n_top * 2
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
 
-void launch_raygen(const LaunchCfg &cfg, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w, uint32_t n_threads) {
+void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
+                   uint32_t n_threads) {
     if (!n_threads) return;
-    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
+    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, sc, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
+}
+
+// workgroups of a persistent kernel that are resident at once (they split the queue statically, so all must run together)
+template <class K> static uint32_t resident_blocks(K kernel, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TRACE_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    return (uint32_t)(cus > 0 ? cus : 256) * (uint32_t)per_cu;
+}
+
+static int trace_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("RT_TRACE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads, bool count) {
     if (!seg_threads) return;
-    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
-    if (count) hipLaunchKernelGGL(k_extend<true>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
-    else hipLaunchKernelGGL(k_extend<false>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+    const int variant = trace_variant();
+    if (variant == 0) { // one ray per lane for the lifetime of the wave
+        dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
+        if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+        else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+        return;
+    }
+    const uint32_t want = (uint32_t)(((unsigned long long)seg_threads * RT_NSEG + TRACE_BLOCK - 1) / TRACE_BLOCK);
+#define TRACE_LAUNCH(K)                                                                                                   \
+    do {                                                                                                                  \
+        static uint32_t res = 0;                                                                                          \
+        if (!res) res = resident_blocks(K, lds_bytes(sc));                                                                \
+        hipLaunchKernelGGL(K, dim3(want < res ? want : res), dim3(TRACE_BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity); \
+    } while (0)
+    if (count) TRACE_LAUNCH((k_trace_closest<true, 24, 16>));
+    else if (variant == 1) TRACE_LAUNCH((k_trace_closest<false, 16, 8>));
+    else if (variant == 2) TRACE_LAUNCH((k_trace_closest<false, 24, 16>));
+    else if (variant == 3) TRACE_LAUNCH((k_trace_closest<false, 32, 24>));
+    else if (variant == 4) TRACE_LAUNCH((k_trace_closest<false, 48, 32>));
+    else if (variant == 5) TRACE_LAUNCH((k_trace_closest<false, 24, 1>));
+    else TRACE_LAUNCH((k_trace_closest<false, 64, 16>));
+#undef TRACE_LAUNCH
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
@@ -647,9 +735,30 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
                    uint32_t seg_threads, bool count) {
     if (!seg_threads) return;
-    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
-    if (count) hipLaunchKernelGGL(k_shadow<true>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
-    else hipLaunchKernelGGL(k_shadow<false>, g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+    const int variant = trace_variant();
+    if (variant == 0) {
+        dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
+        if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+        else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+        else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+        return;
+    }
+    const uint32_t want = (uint32_t)(((unsigned long long)seg_threads * RT_NSEG + TRACE_BLOCK - 1) / TRACE_BLOCK);
+#define TRACE_LAUNCH(K)                                                                                                   \
+    do {                                                                                                                  \
+        static uint32_t res = 0;                                                                                          \
+        if (!res) res = resident_blocks(K, lds_bytes(sc));                                                                \
+        hipLaunchKernelGGL(K, dim3(want < res ? want : res), dim3(TRACE_BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, \
+                           cfg.shadow_seg_capacity);                                                                      \
+    } while (0)
+    if (count) TRACE_LAUNCH((k_trace_shadow<true, 24, 16>));
+    else if (variant == 1) TRACE_LAUNCH((k_trace_shadow<false, 16, 8>));
+    else if (variant == 2) TRACE_LAUNCH((k_trace_shadow<false, 24, 16>));
+    else if (variant == 3) TRACE_LAUNCH((k_trace_shadow<false, 32, 24>));
+    else if (variant == 4) TRACE_LAUNCH((k_trace_shadow<false, 48, 32>));
+    else if (variant == 5) TRACE_LAUNCH((k_trace_shadow<false, 24, 1>));
+    else TRACE_LAUNCH((k_trace_shadow<false, 64, 16>));
+#undef TRACE_LAUNCH
 }
 
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels) {

@@ -513,6 +513,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         HIP_TRY(hipMemcpyAsync(&ctx->ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int cur = 0;
+        ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
         for (;;) {
             launch_plan(cfg, ctx->ctl);
             HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &ctx->ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
@@ -520,42 +521,43 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
             if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
+            // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
+            if (c.max_sh_light || c.max_sh_heavy) {
+                timer.begin(2);
+                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels, std::min(c.max_sh_light, shadow_seg_capacity),
+                              std::min(c.max_sh_heavy, shadow_seg_capacity), count_work);
+                timer.end();
+                st.launches_shadow++;
+            }
             if (c.done) break;
             NodeQueue in{ctx->qa[cur].p, ctx->qb[cur].p, ctx->qc[cur].p};
             NodeQueue out{ctx->qa[cur ^ 1].p, ctx->qb[cur ^ 1].p, ctx->qc[cur ^ 1].p};
-            ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
             if (c.n_new) {
                 timer.begin(3);
                 launch_raygen(cfg, s->dev, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
                 timer.end();
                 st.launches_raygen++;
             }
-            // most nodes any segment can hold after ray generation: what it carried in + its share of the raygen workgroups
+            // most nodes a segment of each class can hold after ray generation: what it carried in + its share of the
+            // raygen workgroups (workgroup b feeds segment b % RT_NSEG_HALF of either class)
             const uint32_t new_blocks = (c.n_new + 255u) / 256u;
-            const uint32_t seg_threads = std::min(seg_capacity, c.max_in + ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * 256u);
+            const uint32_t fresh = ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * 256u;
+            const uint32_t light_threads = std::min(seg_capacity, c.max_in_light + fresh);
+            const uint32_t heavy_threads = s->dev.n_heavy ? std::min(seg_capacity, c.max_in_heavy + fresh) : c.max_in_heavy;
             timer.begin(0);
-            launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, seg_threads, count_work);
+            launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, light_threads, heavy_threads, count_work);
             timer.end();
             st.launches_extend++;
             timer.begin(1);
-            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, seg_threads);
+            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, light_threads, heavy_threads);
             timer.end();
             st.launches_shade++;
-            if (p->shader != RT_SHADER_PATH) {
-                // shade workgroup (bx, s) appends to segments (bx + s) % RT_NSEG_HALF (+ RT_NSEG_HALF for heavy rays): for every
-                // bx exactly two source segments map onto a given target, so it receives from 2 * blocks_x workgroups
-                const uint32_t bx = (seg_threads + 255u) / 256u;
-                const unsigned long long bound = 2ull * bx * 256ull * per_node;
-                timer.begin(2);
-                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels,
-                              (uint32_t)std::min<unsigned long long>(bound, shadow_seg_capacity), count_work);
-                timer.end();
-                st.launches_shadow++;
-            }
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
             cur ^= 1;
         }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        timer.collect();
         const CtlHead c = *ctx->ctl_host;
         st.camera_samples = c.cam_samples;
         st.rays_closest = c.rays_closest;

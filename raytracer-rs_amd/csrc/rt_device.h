@@ -33,6 +33,16 @@ __device__ __forceinline__ F3 mul_v(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y
 __device__ __forceinline__ bool is_black(F3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 __device__ __forceinline__ bool all_finite(F3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
+// ---- approximate division (1 ulp reciprocal) --------------------------------------------------------------------------
+// ONLY for the last scaling step of a quantity that weighs a path (BSDF value, pdf, light term) and for scheduling
+// hints.  Anything that decides where a path goes (hit tests, hit points, normals, sampled directions) uses the IEEE
+// forms above, so paths stay bit-identical with the CPU evaluation.  Unit vectors keep the IEEE normalisation as well:
+// they feed cancelling expressions ((1 - |cos|)^2 in the Fresnel term, wi + wo in the half vector) that would amplify
+// a 1-ulp error to 1e-3; a 1-ulp error in a final quotient stays 1 ulp.
+__device__ __forceinline__ float rcp_w(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float div_w(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ F3 div_w(F3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return F3{a.x * r, a.y * r, a.z * r}; }
+
 #define RTD_PI 3.14159265358979323846f
 #define RTD_ZERO 1.1920928955078125e-07f /* f32::EPSILON, lib.rs:19 */
 
@@ -127,7 +137,8 @@ struct DevScene {
 
 __device__ __forceinline__ bool ray_is_heavy(const DevScene &sc, F3 o, F3 d, float t_min, float t_max) {
     bool heavy = false;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    if (sc.n_heavy == 0) return false;
+    const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z);
     for (int k = 0; k < sc.n_heavy; k++) {
         float x0 = (sc.heavy_min[k][0] - o.x) * ix, x1 = (sc.heavy_max[k][0] - o.x) * ix;
         float y0 = (sc.heavy_min[k][1] - o.y) * iy, y1 = (sc.heavy_max[k][1] - o.y) * iy;
@@ -261,7 +272,7 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
     if (sc.n_nodes == 0) return best;
     const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * 32u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
     int node = 0;
     while (node >= 0) {
         u32x4 na, nb;
@@ -396,7 +407,7 @@ __device__ __forceinline__ int lights_hit(const DevScene &sc, F3 o, F3 d, float 
 __device__ __forceinline__ float disk_pdf(const DevLight &L, F3 dir, float sq_dist) {
     float area = RTD_PI * (L.radius * L.radius);
     float cosine = fabsf(dot(dir, f3(0.0f, 1.0f, 0.0f)));
-    return sq_dist / (cosine * area);
+    return div_w(sq_dist, cosine * area);
 }
 
 // Light::pdf once the light's own hit distance is known: light.rs:97-99, 215-221, 334-342
@@ -405,7 +416,7 @@ __device__ __forceinline__ float light_pdf_with_t(const DevLight &L, F3 d, bool 
     float sq_dist = (t * t) * dot(d, d);
     if (L.kind == RT_LIGHT_DISK) return disk_pdf(L, d, sq_dist);
     float cosine = fabsf(dot(d, f3(L.nx, L.ny, L.nz)));
-    return sq_dist / (cosine * L.area);
+    return div_w(sq_dist, cosine * L.area);
 }
 
 // ------------------------------------------------------------------------------------------------ samplers
@@ -510,14 +521,14 @@ __device__ __forceinline__ float ggx_distribution(F3 n, F3 h, float alpha) {
     float noh2 = noh * noh;
     float alpha2 = alpha * alpha;
     float e = noh2 * (alpha2 - 1.0f) + 1.0f;
-    return alpha2 / (RTD_PI * (e * e));
+    return div_w(alpha2, RTD_PI * (e * e));
 }
-__device__ __forceinline__ float ggx_schlick(float nov, float k) { return nov / (k + (1.0f - k) * nov); }
+__device__ __forceinline__ float ggx_schlick(float nov, float k) { return div_w(nov, k + (1.0f - k) * nov); }
 __device__ __forceinline__ float ggx_partial_geometry_term(F3 l, F3 v, F3 n, float alpha) {
     float nol = fabsf(dot(n, l));
     float nov = fabsf(dot(n, v));
     float r = sqrtf(alpha);
-    float k = ((r + 1.0f) * (r + 1.0f)) / 8.0f;
+    float k = ((r + 1.0f) * (r + 1.0f)) * 0.125f;
     return ggx_schlick(nol, k) * ggx_schlick(nov, k);
 }
 __device__ __forceinline__ F3 fresnel_schlick(F3 din, F3 dnor, F3 f0) {
@@ -540,7 +551,7 @@ __device__ __forceinline__ void get_local_coordinate(F3 v1, F3 *bx, F3 *by, F3 *
 __device__ __forceinline__ void mat_brdf_pdf(const rt_material &m, F3 din, F3 dout, F3 dnor, float t_min, F3 *brdf, float *pdf) {
     switch (m.kind) {
     case RT_MAT_DIFFUSE:
-        *brdf = albedo_of(m) / RTD_PI;
+        *brdf = albedo_of(m) * (1.0f / RTD_PI);
         *pdf = 1.0f / RTD_PI;
         return;
     case RT_MAT_METAL: {
@@ -565,15 +576,15 @@ __device__ __forceinline__ void mat_brdf_pdf(const rt_material &m, F3 din, F3 do
             float a2 = alpha * alpha;
             float cos_theta = fabsf(dot(wg, wm));
             float e = (a2 - 1.0f) * (cos_theta * cos_theta) + 1.0f;
-            float dd = a2 / (RTD_PI * (e * e));
-            *pdf = (dd * cos_theta) / (4.0f * fabsf(dot(wo, wm)));
+            float dd = div_w(a2, RTD_PI * (e * e));
+            *pdf = div_w(dd * cos_theta, 4.0f * fabsf(dot(wo, wm)));
         }
         if (dot(wi, wg) <= 0.0f || dot(wi, wm) <= 0.0f) { *brdf = f3(0.0f, 0.0f, 0.0f); return; }
         F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
         F3 f = fresnel_schlick(wi, wg, f0);
         float dterm = ggx_distribution(wg, wm, alpha);
         float g = ggx_partial_geometry_term(wi, wo, wg, alpha);
-        F3 res = (f * dterm * g) / (4.0f * fabsf(dot(wg, wi)) * fabsf(dot(wg, wo)));
+        F3 res = div_w(f * dterm * g, 4.0f * fabsf(dot(wg, wi)) * fabsf(dot(wg, wo)));
         *brdf = mul_v(albedo_of(m), res);
         return;
     }

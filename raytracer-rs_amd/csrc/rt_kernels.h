@@ -40,15 +40,14 @@ struct SegCounter {
 struct CtlHead {
     uint32_t n_alive;   // nodes carried into this iteration (before ray generation)
     uint32_t n_new;     // camera candidates to generate this iteration
-    uint32_t max_in;    // largest per-segment node count before ray generation
-    uint32_t max_shadow_prev; // largest per-segment shadow count of the previous iteration (diagnostic)
+    uint32_t max_in_light, max_in_heavy; // largest per-segment node count of each class before ray generation
+    uint32_t max_sh_light, max_sh_heavy; // largest per-segment shadow-ray count queued by the previous iteration
     uint32_t first_sample;    // sample index (relative to spp_begin) of the first camera candidate of this iteration
     uint32_t first_rem;       // ... and its position inside that sample
     uint32_t per_sample;      // camera candidates per sample = 64 * number of 8x8 pixel blocks
     uint32_t iterations;
     uint32_t done;      // nothing left to do
     uint32_t overflow;  // a queue segment ran out of room (the render call fails)
-    uint32_t pad0, pad1;
     unsigned long long cursor; // next camera candidate not yet generated
     unsigned long long total;  // all camera candidates of this render call
     unsigned long long rays_closest, rays_shadow, cam_samples, nodes, tris;
@@ -58,7 +57,8 @@ struct Ctl {
     CtlHead h;
     SegCounter seg_in[RT_NSEG];     // nodes per segment of the current queue
     SegCounter seg_out[RT_NSEG];    // nodes appended per segment of the next queue
-    SegCounter seg_shadow[RT_NSEG]; // shadow rays per segment
+    SegCounter seg_shadow[RT_NSEG]; // shadow rays per segment, being filled by k_shade
+    uint32_t seg_shadow_cur[RT_NSEG]; // ... of the previous iteration, being consumed by k_shadow
 };
 
 struct LaunchCfg {
@@ -69,15 +69,16 @@ struct LaunchCfg {
 };
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl);
-// seg_threads = upper bound of the elements in any one segment (the grid is ceil(seg_threads/256) x RT_NSEG)
+// Consumer grids are one-dimensional: RT_NSEG_HALF * heavy_blocks workgroups for the heavy segments first (they run
+// longest), then RT_NSEG_HALF * light_blocks for the light ones; *_threads = most elements in any one segment of the class.
 void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                    uint32_t n_threads);
-void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads,
-                   bool count);
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t light_threads,
+                   uint32_t heavy_threads, bool count);
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out,
-                  const float4 *hit, ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_threads);
+                  const float4 *hit, ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads);
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                   uint32_t seg_threads, bool count);
+                   uint32_t light_threads, uint32_t heavy_threads, bool count);
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels);
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t);
 void launch_planes_to_rgb(const LaunchCfg &cfg, const float *planes, float *accum_rgb, uint32_t n_pixels);

@@ -80,6 +80,19 @@ __device__ __forceinline__ void add_pixel(float *planes, uint32_t n_pixels, uint
     atomicAdd(planes + 2u * n_pixels + pixel, c.z);
 }
 
+// one-dimensional consumer grid -> (segment, workgroup index inside the segment): heavy segments first
+__device__ __forceinline__ void decode_block(uint32_t b, uint32_t heavy_blocks, uint32_t *seg, uint32_t *bx) {
+    const uint32_t nh = heavy_blocks * RT_NSEG_HALF;
+    if (b < nh) {
+        *seg = RT_NSEG_HALF + b % RT_NSEG_HALF;
+        *bx = b / RT_NSEG_HALF;
+    } else {
+        b -= nh;
+        *seg = b % RT_NSEG_HALF;
+        *bx = b / RT_NSEG_HALF;
+    }
+}
+
 struct Node {
     F3 o, d, w;
     float b_pdf;
@@ -114,17 +127,19 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
         s_sh[t] = ctl->seg_shadow[t].v;
         ctl->seg_in[t].v = s_out[t]; // the queue filled by the last iteration becomes the current one
         ctl->seg_out[t].v = 0;
+        ctl->seg_shadow_cur[t] = s_sh[t]; // k_shadow of the last iteration runs after this kernel, with exact counts
         ctl->seg_shadow[t].v = 0;
     }
     __syncthreads();
     if (t != 0) return;
-    uint32_t prev_in = 0, alive = 0, prev_shadow = 0, max_in = 0, max_sh = 0;
+    uint32_t prev_in = 0, alive = 0, prev_shadow = 0, max_in[2] = {0, 0}, max_sh[2] = {0, 0};
     for (int k = 0; k < RT_NSEG; k++) {
+        const int cls = k / RT_NSEG_HALF;
         prev_in += s_in[k];
         alive += s_out[k];
         prev_shadow += s_sh[k];
-        max_in = s_out[k] > max_in ? s_out[k] : max_in;
-        max_sh = s_sh[k] > max_sh ? s_sh[k] : max_sh;
+        max_in[cls] = s_out[k] > max_in[cls] ? s_out[k] : max_in[cls];
+        max_sh[cls] = s_sh[k] > max_sh[cls] ? s_sh[k] : max_sh[cls];
     }
     CtlHead &h = ctl->h;
     // close the iteration that just ran: it extended prev_in nodes, n_alive of which were carried in, the rest new camera rays
@@ -142,8 +157,10 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     h.cursor += n_new;
     h.n_new = n_new;
     h.n_alive = alive;
-    h.max_in = max_in;
-    h.max_shadow_prev = max_sh;
+    h.max_in_light = max_in[0];
+    h.max_in_heavy = max_in[1];
+    h.max_sh_light = max_sh[0];
+    h.max_sh_heavy = max_sh[1];
     h.done = (alive == 0 && n_new == 0) ? 1u : 0u;
     if (!h.done) h.iterations++;
 }
@@ -199,16 +216,18 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, C
 // grid (blocks, RT_NSEG): workgroup (bx, s) handles nodes [bx*256, bx*256+256) of segment s.
 // hit record: (t_obj, object code, -, -)
 template <bool COUNT, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity) {
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity,
+                                                  uint32_t heavy_blocks) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t seg = RT_NSEG - 1u - blockIdx.y; // heavy segments first: their workgroups run longest
+    uint32_t seg, bx;
+    decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
-    if (blockIdx.x * BLOCK >= n_seg) return;
+    if (bx * BLOCK >= n_seg) return;
     if (USE_LDS) {
         for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
         __syncthreads();
     }
-    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t il = bx * BLOCK + threadIdx.x;
     if (il >= n_seg) return;
     const uint32_t i = seg * seg_capacity + il;
     float4 a = in.a[i], b = in.b[i];
@@ -230,8 +249,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, Rend
     extern __shared__ float4 lds_nodes[];
     __shared__ int chunk_prefix[RT_NSEG + 1];
     __shared__ uint32_t seg_count[RT_NSEG];
-    trace_persistent<false, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_in[0].v, seg_capacity, in.a, in.b, nullptr, hit, nullptr, 0u, lds_nodes,
-                                                   chunk_prefix, seg_count);
+    trace_persistent<false, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_in[0].v, (uint32_t)(sizeof(SegCounter) / sizeof(uint32_t)), seg_capacity, in.a, in.b,
+                                                   nullptr, hit, nullptr, 0u, lds_nodes, chunk_prefix, seg_count);
 }
 
 template <bool COUNT, int REFILL, int LEAF_T>
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, Rende
     extern __shared__ float4 lds_nodes[];
     __shared__ int chunk_prefix[RT_NSEG + 1];
     __shared__ uint32_t seg_count[RT_NSEG];
-    trace_persistent<true, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_shadow[0].v, shadow_seg_capacity, sh.a, sh.b, sh.c, nullptr, planes, n_pixels,
+    trace_persistent<true, COUNT, REFILL, LEAF_T>(sc, rc, ctl, ctl->seg_shadow_cur, 1u, shadow_seg_capacity, sh.a, sh.b, sh.c, nullptr, planes, n_pixels,
                                                   lds_nodes, chunk_prefix, seg_count);
 }
 
@@ -296,7 +315,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst
     if (L.kind == RT_LIGHT_POINT) {
         F3 dir = f3(L.ox, L.oy, L.oz) - p;
         *dir_out = dir;
-        *radiance = spectrum * dot(normalize(dir), normalize(n)) / dot(dir, dir); // light.rs:79
+        *radiance = div_w(spectrum * dot(normalize(dir), normalize(n)), dot(dir, dir)); // light.rs:79
         *p_light = RTD_ZERO;
         return true;
     }
@@ -330,14 +349,15 @@ __device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst
 template <int SHADER>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
-                                                 uint32_t shadow_seg_capacity) {
+                                                 uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     __shared__ BlockAppend sm;
-    const uint32_t seg = blockIdx.y;
+    uint32_t seg, bx;
+    decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
-    if (blockIdx.x * BLOCK >= n_seg) return;
-    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    if (bx * BLOCK >= n_seg) return;
+    const uint32_t il = bx * BLOCK + threadIdx.x;
     const uint32_t i = seg * seg_capacity + il;
-    const uint32_t oseg_l = (blockIdx.x + seg) % RT_NSEG_HALF, oseg_h = RT_NSEG_HALF + oseg_l;
+    const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF, oseg_h = RT_NSEG_HALF + oseg_l;
 
     bool have0 = false, have1 = false, have_s = false;
     Node c0, c1;
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
         F3 beta = nd.w;
         if (SHADER == RT_SHADER_MIS && !root) {
             float l_pdf = li >= 0 ? light_pdf_with_t(sc.lights[li], nd.d, true, t_l) : RTD_ZERO; // LightList::pdf, light.rs:399-405
-            beta = nd.w / (l_pdf + nd.b_pdf);
+            beta = div_w(nd.w, l_pdf + nd.b_pdf);
         }
         const bool obj = code != HIT_NONE;
         const bool light_wins = li >= 0 && (!obj || !(t_l > t_obj)); // shader.rs:101,108-112
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                     F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
                     F3 f = fresnel_schlick(dd, n, f0);
                     F3 kd = (f3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
-                    F3 w = mul_v(beta, mul_v(kd, albedo_of(m) / RTD_PI));
+                    F3 w = mul_v(beta, mul_v(kd, albedo_of(m) * (1.0f / RTD_PI)));
                     uint32_t dmin = (uint32_t)max(rc.max_depth - 6, 0); // depth.max(34) for the reference's 40
                     uint32_t d1 = max(depth, dmin) + 1u;
                     if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                     F3 brdf;
                     float pdf;
                     mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
-                    F3 direct = mul_v(radiance, brdf) / (p_l + pdf);
+                    F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
                     F3 c = mul_v(beta, direct);
                     if (!is_black(c)) {
                         have_s = true;
@@ -563,16 +583,17 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
 // ---- k_shadow --------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                                                  uint32_t shadow_seg_capacity) {
+                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     extern __shared__ float4 lds_nodes[];
-    const uint32_t seg = RT_NSEG - 1u - blockIdx.y;
-    const uint32_t n = min(ctl->seg_shadow[seg].v, shadow_seg_capacity);
-    if (blockIdx.x * BLOCK >= n) return;
+    uint32_t seg, bx;
+    decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    const uint32_t n = min(ctl->seg_shadow_cur[seg], shadow_seg_capacity);
+    if (bx * BLOCK >= n) return;
     if (USE_LDS) {
         for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
         __syncthreads();
     }
-    const uint32_t il = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t il = bx * BLOCK + threadIdx.x;
     if (il >= n) return;
     const uint32_t i = seg * shadow_seg_capacity + il;
     float4 a = sh.a[i], b = sh.b[i];
@@ -693,17 +714,25 @@ static int trace_variant() {
     return v;
 }
 
-void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_threads, bool count) {
-    if (!seg_threads) return;
+static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads, uint32_t *heavy_blocks) {
+    *heavy_blocks = nblocks(heavy_threads);
+    return RT_NSEG_HALF * (*heavy_blocks + nblocks(light_threads));
+}
+
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t light_threads,
+                   uint32_t heavy_threads, bool count) {
+    uint32_t hb;
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    if (!grid) return;
     const int variant = trace_variant();
     if (variant == 0) { // one ray per lane for the lifetime of the wave
-        dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
-        if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
-        else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
-        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity);
+        dim3 g(grid), b(BLOCK);
+        if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+        else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
         return;
     }
-    const uint32_t want = (uint32_t)(((unsigned long long)seg_threads * RT_NSEG + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    const uint32_t want = grid;
 #define TRACE_LAUNCH(K)                                                                                                   \
     do {                                                                                                                  \
         static uint32_t res = 0;                                                                                          \
@@ -713,37 +742,38 @@ void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     if (count) TRACE_LAUNCH((k_trace_closest<true, 24, 16>));
     else if (variant == 1) TRACE_LAUNCH((k_trace_closest<false, 16, 8>));
     else if (variant == 2) TRACE_LAUNCH((k_trace_closest<false, 24, 16>));
-    else if (variant == 3) TRACE_LAUNCH((k_trace_closest<false, 32, 24>));
-    else if (variant == 4) TRACE_LAUNCH((k_trace_closest<false, 48, 32>));
-    else if (variant == 5) TRACE_LAUNCH((k_trace_closest<false, 24, 1>));
-    else TRACE_LAUNCH((k_trace_closest<false, 64, 16>));
+    else TRACE_LAUNCH((k_trace_closest<false, 24, 1>));
 #undef TRACE_LAUNCH
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
-                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_threads) {
-    if (!seg_threads) return;
-    dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
+                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads) {
+    uint32_t hb;
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    if (!grid) return;
+    dim3 g(grid), b(BLOCK);
     if (shader == RT_SHADER_MIS)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else if (shader == RT_SHADER_PATH)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else
-        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity);
+        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
 }
 
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                   uint32_t seg_threads, bool count) {
-    if (!seg_threads) return;
+                   uint32_t light_threads, uint32_t heavy_threads, bool count) {
+    uint32_t hb;
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    if (!grid) return;
     const int variant = trace_variant();
     if (variant == 0) {
-        dim3 g(nblocks(seg_threads), RT_NSEG), b(BLOCK);
-        if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
-        else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
-        else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity);
+        dim3 g(grid), b(BLOCK);
+        if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+        else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+        else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
         return;
     }
-    const uint32_t want = (uint32_t)(((unsigned long long)seg_threads * RT_NSEG + TRACE_BLOCK - 1) / TRACE_BLOCK);
+    const uint32_t want = grid;
 #define TRACE_LAUNCH(K)                                                                                                   \
     do {                                                                                                                  \
         static uint32_t res = 0;                                                                                          \
@@ -754,10 +784,7 @@ void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     if (count) TRACE_LAUNCH((k_trace_shadow<true, 24, 16>));
     else if (variant == 1) TRACE_LAUNCH((k_trace_shadow<false, 16, 8>));
     else if (variant == 2) TRACE_LAUNCH((k_trace_shadow<false, 24, 16>));
-    else if (variant == 3) TRACE_LAUNCH((k_trace_shadow<false, 32, 24>));
-    else if (variant == 4) TRACE_LAUNCH((k_trace_shadow<false, 48, 32>));
-    else if (variant == 5) TRACE_LAUNCH((k_trace_shadow<false, 24, 1>));
-    else TRACE_LAUNCH((k_trace_shadow<false, 64, 16>));
+    else TRACE_LAUNCH((k_trace_shadow<false, 24, 1>));
 #undef TRACE_LAUNCH
 }
 

@@ -47,12 +47,12 @@ __device__ __forceinline__ void cursor_seek(TraceCursor &w, int chunk, const int
 // ANY_HIT = true : occlusion query (light.rs:74,170,200,320); unoccluded rays add their contribution to the frame.
 template <bool ANY_HIT, bool COUNT, int REFILL, int LEAF_T>
 __device__ __forceinline__ void trace_persistent(const DevScene &sc, const RenderConst &rc, Ctl *ctl, const uint32_t *seg_count_global,
-                                                 uint32_t seg_capacity, const float4 *ray_a, const float4 *ray_b, const float2 *ray_c,
+                                                 uint32_t seg_count_stride, uint32_t seg_capacity, const float4 *ray_a, const float4 *ray_b, const float2 *ray_c,
                                                  float4 *hit, float *planes, uint32_t n_pixels, float4 *lds_nodes, int *chunk_prefix,
                                                  uint32_t *seg_count) {
     // ---- per-workgroup prologue: segment counts, chunk prefix, top of the tree
     if (threadIdx.x < RT_NSEG) {
-        uint32_t c = seg_count_global[threadIdx.x * (sizeof(SegCounter) / sizeof(uint32_t))];
+        uint32_t c = seg_count_global[threadIdx.x * seg_count_stride];
         seg_count[threadIdx.x] = c < seg_capacity ? c : seg_capacity;
     }
     for (int j = threadIdx.x; j < 2 * sc.n_top; j += TRACE_BLOCK) lds_nodes[j] = sc.nodes[j];

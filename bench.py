@@ -41,6 +41,7 @@ def main() -> int:
     ap.add_argument("--spp", type=int, default=0, help="override the workload's samples per pixel (invalidates the headline number)")
     ap.add_argument("--shard", default="spp", choices=["spp", "tile"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-count-pass", action="store_true", help="skip the untimed BVH work-counting pass (for PMC profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
@@ -122,32 +123,61 @@ def main() -> int:
         ms_per_step = elapsed / steps * 1e3
         mrays = total_rays / elapsed / 1e6
 
-        # ---- roofline of the dominant kernel (k_extend: closest-hit traversal), from this rank's timed steps
-        ms_ext = sum(s.ms_extend for s in stats)
-        n_ext = sum(s.launches_extend for s in stats)
-        rays_ext = sum(s.rays_closest for s in stats)
+        # ---- roofline of the dominant kernel, from this rank's timed steps (HIP events on the render stream)
+        # Algorithmic HBM bytes per unit (DESIGN.md "Kernels"): what one launch must stream to and from HBM.  BVH nodes and
+        # triangles are NOT in these figures: the whole scene (a few MB) stays in L2 / Infinity Cache / LDS after the first
+        # touch; their per-ray volume is reported beside it as cache_bytes_per_ray.
+        closest = sum(s.rays_closest for s in stats)
+        shadow = sum(s.rays_shadow for s in stats)
+        cams = sum(s.camera_samples for s in stats)
+        children_per_node = (closest - cams) / max(1, closest)
+        shadow_per_node = shadow / max(1, closest)
         stage_ms = {k: sum(getattr(s, "ms_" + k) for s in stats) / steps for k in ("extend", "shade", "shadow", "raygen")}
-        # mean BVH work per closest-hit ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
-        cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK)
-        cp.spp_begin, cp.spp_end = 0, 1
-        scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize()
-        cst = ds.render_device(hs.camera, cp, scratch.data_ptr())
-        n_rays_counted = max(1, cst.rays_closest + cst.rays_shadow)
-        nodes_per_ray = cst.nodes_visited / n_rays_counted
-        tris_per_ray = cst.tris_tested / n_rays_counted
+        # mean BVH work per ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
+        nodes_per_ray = tris_per_ray = 0.0
+        if not args.no_count_pass:
+            cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK)
+            cp.spp_begin, cp.spp_end = 0, 1
+            scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            cst = ds.render_device(hs.camera, cp, scratch.data_ptr())
+            n_rays_counted = max(1, cst.rays_closest + cst.rays_shadow)
+            nodes_per_ray = cst.nodes_visited / n_rays_counted
+            tris_per_ray = cst.tris_tested / n_rays_counted
         d = hs.desc
-        bytes_per_ray = 32 + 16 + 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
+        cache_bytes_per_ray = 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
+        per_unit = {  # kernel: (units over the timed steps, algorithmic HBM bytes per unit, launches, total ms)
+            "k_extend": (closest, 32 + 16, sum(s.launches_extend for s in stats), sum(s.ms_extend for s in stats)),
+            "k_shade": (closest, 48 + 16 + 48 * children_per_node + 40 * shadow_per_node, sum(s.launches_shade for s in stats), sum(s.ms_shade for s in stats)),
+            "k_shadow": (shadow, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        measured_traffic = {}
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload and not args.spp:
+                measured_traffic = tj.get("bytes_per_launch", {})
+        kernels = {}
+        for name, (units, bpu, launches, ms) in per_unit.items():
+            if launches and ms > 0:
+                avg_ms = ms / launches
+                achieved = bpu * (units / launches) / (avg_ms * 1e-3) / 1e9
+                kernels[name] = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round(achieved / 8000.0, 4), "traffic": measured_traffic.get(name), "avg_launch_ms": round(avg_ms, 4),
+                                 "launches_per_step": launches / steps, "units_per_launch": round(units / launches, 1),
+                                 "bytes_per_unit": round(bpu, 1), "ms_per_step": round(ms / steps, 2)}
         roofline = None
-        if n_ext and ms_ext > 0:
-            avg_ms = ms_ext / n_ext
-            rays_per_launch = rays_ext / n_ext
-            achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(achieved / 8000.0, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                        "launches_per_step": n_ext / steps, "rays_per_launch": round(rays_per_launch, 1),
-                        "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
-                        "tris_per_ray": round(tris_per_ray, 2)}
+        if kernels:
+            dom = max(kernels.values(), key=lambda k: k["ms_per_step"])
+            roofline = dict(dom)
+            roofline["note"] = ("HBM roofline of the kernel with the largest share of the step; traversal kernels are bound by divergence and "
+                                "L1/L2 latency, not HBM: BVH/triangle fetches (cache_bytes_per_ray) never leave the caches")
+            roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)
+            roofline["nodes_per_ray"] = round(nodes_per_ray, 2)
+            roofline["tris_per_ray"] = round(tris_per_ray, 2)
+            roofline["all_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "avg_launch_ms", "bytes_per_unit", "ms_per_step", "traffic")}
+                                       for k, v in kernels.items()}
 
         # ---- CPU baseline: the oracle (a restatement of the reference, not the Rust binary) on a bounded sample
         cpu = None

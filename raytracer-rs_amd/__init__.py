@@ -282,7 +282,7 @@ def hip_lib() -> C.CDLL:
     """Loads librt_hip.so.  Raises ImportError if it has not been built: there is no CPU substitute."""
     global _hip
     if _hip is None:
-        path = os.path.join(LIB_DIR, "librt_hip.so")
+        path = os.environ.get("RT_HIP_LIB") or os.path.join(LIB_DIR, "librt_hip.so")  # RT_HIP_LIB: A/B builds of the same ABI
         if not os.path.exists(path):
             raise ImportError(f"{path} is missing: run `make` at the repository root (needs hipcc)")
         _share_hip_runtime_with_torch()

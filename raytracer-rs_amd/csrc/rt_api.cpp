@@ -121,7 +121,7 @@ void tri_normal_area(const float *v, float *n, float *area) { // geometry.rs:16-
 
 int check_params(const rt_params &p) {
     if (p.width <= 0 || p.height <= 0 || p.spp <= 0) return fail(RT_ERR_INVALID, "width, height and spp must be positive");
-    if ((long long)p.width * p.height > (1ll << 24)) return fail(RT_ERR_INVALID, "at most 2^24 pixels per frame");
+    if ((long long)p.width * p.height > (1ll << 24) || p.width > 65536) return fail(RT_ERR_INVALID, "at most 2^24 pixels per frame and 65536 per row");
     if (p.spp_begin < 0 || p.spp_end < p.spp_begin || p.spp_end > p.spp) return fail(RT_ERR_INVALID, "bad sample range");
     if (p.shader < RT_SHADER_NORMAL || p.shader > RT_SHADER_MIS) return fail(RT_ERR_INVALID, "bad shader");
     if (p.pixel_sampler < RT_SAMPLER_WHITE || p.pixel_sampler > RT_SAMPLER_BLUE) return fail(RT_ERR_INVALID, "unexpected integer"); // sampler.rs:19
@@ -150,6 +150,9 @@ RenderConst make_const(const rt_camera &cam, const rt_params &p) {
     rc.spp_edge = (int)std::sqrt((double)p.spp);           // sampler.rs:104
     rc.ns2_edge = (int)std::sqrt((double)p.light_samples);
     rc.t_min = p.t_min; rc.t_max = p.t_max; rc.seed = p.seed;
+    rc.tiles_w = (uint32_t)((p.width + 7) / 8);
+    rc.plane_stride = 64u * rc.tiles_w * (uint32_t)((p.height + 7) / 8);
+    rc.w_magic = ((1ull << 40) + (unsigned long long)p.width - 1ull) / (unsigned long long)p.width;
     return rc;
 }
 
@@ -345,6 +348,18 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
             }
             L.area = area;
             L.nx = n0[0]; L.ny = n0[1]; L.nz = n0[2];
+            for (int a = 0; a < 3; a++) { L.bmin[a] = 1e30f; L.bmax[a] = -1e30f; }
+            for (int v = 0; v < l.tri_count * 3; v++) {
+                const float *q = d->light_tri_v + 9 * (size_t)l.tri_first + 3 * (size_t)v;
+                for (int a = 0; a < 3; a++) { L.bmin[a] = std::min(L.bmin[a], q[a]); L.bmax[a] = std::max(L.bmax[a], q[a]); }
+            }
+            float ext = 0.0f, mag = 0.0f;
+            for (int a = 0; a < 3; a++) {
+                ext = std::max(ext, L.bmax[a] - L.bmin[a]);
+                mag = std::max(mag, std::max(std::fabs(L.bmin[a]), std::fabs(L.bmax[a])));
+            }
+            const float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f; // same padding as the BVH leaves
+            for (int a = 0; a < 3; a++) { L.bmin[a] -= pad; L.bmax[a] += pad; }
         } else if (l.kind == RT_LIGHT_DISK) {
             if (l.sampler_kind < RT_SAMPLER_WHITE || l.sampler_kind > RT_SAMPLER_BLUE) return fail(RT_ERR_INVALID, "unexpected integer");
         } else if (l.kind != RT_LIGHT_POINT) return fail(RT_ERR_INVALID, "bad light kind");
@@ -487,11 +502,12 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
     const uint32_t seg_capacity = 8u * (target / RT_NSEG);
     const uint32_t shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
-    rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, n_pixels);
+    const size_t plane_stride = rcst.plane_stride; // the kernels index the colour planes by tile
+    rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, plane_stride);
     if (rc) return rc;
 
     LaunchCfg cfg{ctx->stream, seg_capacity, shadow_seg_capacity, target};
-    HIP_TRY(hipMemsetAsync(ctx->planes.p, 0, 3 * n_pixels * sizeof(float), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->planes.p, 0, 3 * plane_stride * sizeof(float), ctx->stream));
 
     rt_stats st;
     std::memset(&st, 0, sizeof(st));
@@ -524,7 +540,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
             if (c.max_sh_light || c.max_sh_heavy) {
                 timer.begin(2);
-                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)n_pixels, std::min(c.max_sh_light, shadow_seg_capacity),
+                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)plane_stride, std::min(c.max_sh_light, shadow_seg_capacity),
                               std::min(c.max_sh_heavy, shadow_seg_capacity), count_work);
                 timer.end();
                 st.launches_shadow++;
@@ -549,7 +565,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             timer.end();
             st.launches_extend++;
             timer.begin(1);
-            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)n_pixels, light_threads, heavy_threads);
+            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)plane_stride, light_threads, heavy_threads);
             timer.end();
             st.launches_shade++;
             hipError_t le = hipGetLastError();
@@ -569,12 +585,12 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
 
     // add the planes into the caller's interleaved sum buffer
     if (accum_is_device) {
-        launch_planes_to_rgb(cfg, ctx->planes.p, accum_rgb, (uint32_t)n_pixels);
+        launch_planes_to_rgb(cfg, rcst, ctx->planes.p, accum_rgb, (uint32_t)n_pixels);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     } else {
         HIP_TRY(ctx->accum_tmp.ensure(3 * n_pixels));
         HIP_TRY(hipMemcpyAsync(ctx->accum_tmp.p, accum_rgb, 3 * n_pixels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        launch_planes_to_rgb(cfg, ctx->planes.p, ctx->accum_tmp.p, (uint32_t)n_pixels);
+        launch_planes_to_rgb(cfg, rcst, ctx->planes.p, ctx->accum_tmp.p, (uint32_t)n_pixels);
         HIP_TRY(hipMemcpyAsync(accum_rgb, ctx->accum_tmp.p, 3 * n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }

@@ -107,6 +107,7 @@ struct DevLight {
     int32_t sampler_kind;
     float area;       // PolygonLight::new, light.rs:252-269
     float nx, ny, nz; // normal of face 0
+    float bmin[3], bmax[3]; // polygon light: padded box of its faces, a conservative gate in front of the exact tests
 };
 
 // BVH node, 32 B: a = (bmin.xyz, link), b = (bmax.xyz, miss).  link >= 0: index of the first child (inner node);
@@ -158,7 +159,19 @@ struct RenderConst {
     int32_t spp_edge, ns2_edge; // floor(sqrt(spp)), floor(sqrt(light_samples)): UniformSampler::new, sampler.rs:104
     float t_min, t_max;
     uint32_t seed;
+    // accumulation planes are stored in 8x8 pixel tiles (64 consecutive floats per tile): the lanes of a wave mostly
+    // work on one tile of one sample, so a wave's atomic adds fall into two cache lines instead of eight
+    uint32_t tiles_w;            // ceil(width / 8)
+    uint32_t plane_stride;       // floats per colour plane = 64 * tiles_w * ceil(height / 8)
+    unsigned long long w_magic;  // ceil(2^40 / width): y = (pixel * w_magic) >> 40 for pixel < 2^24
 };
+
+// linear pixel (y*W + x) -> index inside a tiled colour plane
+__device__ __forceinline__ uint32_t tiled_index(const RenderConst &rc, uint32_t pixel) {
+    const uint32_t y = (uint32_t)(((unsigned long long)pixel * rc.w_magic) >> 40);
+    const uint32_t x = pixel - y * (uint32_t)rc.width;
+    return (((y >> 3) * rc.tiles_w + (x >> 3)) << 6) | ((y & 7u) << 3) | (x & 7u);
+}
 
 // hit codes written by the extend stage
 #define HIT_NONE (-1)
@@ -390,7 +403,18 @@ __device__ __forceinline__ bool light_hit(const DevScene &sc, const DevLight &L,
         if (rx * rx + rz * rz <= L.radius * L.radius) { *t_out = hit_t; return true; }
         return false;
     }
-    if (L.kind == RT_LIGHT_POLYGON) return light_mesh_hit(sc, L, o, d, t_min, t_max, t_out);
+    if (L.kind == RT_LIGHT_POLYGON) {
+        // most rays do not point at the light: a slab test against its padded box (culling only, like a BVH node) skips
+        // the two-sided triangle tests with their IEEE divisions
+        const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z);
+        const float x0 = (L.bmin[0] - o.x) * ix, x1 = (L.bmax[0] - o.x) * ix;
+        const float y0 = (L.bmin[1] - o.y) * iy, y1 = (L.bmax[1] - o.y) * iy;
+        const float z0 = (L.bmin[2] - o.z) * iz, z1 = (L.bmax[2] - o.z) * iz;
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+        if (!(tn <= tf * 1.00001f + 1e-7f)) return false;
+        return light_mesh_hit(sc, L, o, d, t_min, t_max, t_out);
+    }
     return false;
 }
 

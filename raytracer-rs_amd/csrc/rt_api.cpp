@@ -384,8 +384,9 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     } while (0)
 
     BvhBuild bvh;
-    const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 128);
-    build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, &bvh);
+    const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 32);
+    const bool ordered = env_u32_allow_zero("RT_BVH_ORDERED", 1) != 0;
+    build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, ordered, &bvh);
     UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
     UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
     UP(s->sph, d->sph, d->n_sph, float4);
@@ -403,7 +404,7 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
 
     s->dev.nodes = s->nodes.p; s->dev.tris = s->tris.p; s->dev.sph = s->sph.p; s->dev.sph_info = s->sph_info.p;
     s->dev.cyl = s->cyl.p; s->dev.cyl_info = s->cyl_info.p; s->dev.mats = s->mats.p; s->dev.lights = s->lights.p; s->dev.ltris = s->ltris.p;
-    s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
+    s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_orders = bvh.n_orders; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
     s->dev.n_light = d->n_light;
     // boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box)
     {
@@ -580,6 +581,14 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         st.rays_shadow = c.rays_shadow;
         st.nodes_visited = c.nodes;
         st.tris_tested = c.tris;
+        if ((p->flags & RT_FLAG_COUNT_WORK) && getenv("RT_DUMP_HIST")) { // development aid: distribution of closest-hit walk lengths
+            std::fprintf(stderr, "[rt] closest-hit walks: bucket b = visited nodes in [2^(b-1), 2^b)\n[rt] rays :");
+            for (int b = 0; b < 16; b++) std::fprintf(stderr, " %llu", c.hist_ray[b]);
+            std::fprintf(stderr, "\n[rt] waves:");
+            for (int b = 0; b < 16; b++) std::fprintf(stderr, " %llu", c.hist_wave[b]);
+            std::fprintf(stderr, "\n[rt] sum of per-wave longest walk %llu (x64 lanes = %llu lane-steps paid for, %llu used)\n", c.wave_steps, c.wave_steps * 64ull,
+                         c.nodes);
+        }
         st.iterations = c.iterations;
     }
 

@@ -1,4 +1,4 @@
-// rt_bvh.cpp — binned-SAH BVH over all world triangles, emitted as a threaded node array (see rt_bvh.h).
+// rt_bvh.cpp — binned-SAH BVH over all world triangles, emitted as threaded node arrays (see rt_bvh.h).
 
 #include "rt_bvh.h"
 
@@ -31,7 +31,8 @@ struct Box {
 
 struct TmpNode {
     Box box;
-    int left = -1, right = -1; // children (inner)
+    int left = -1, right = -1; // children (inner): left holds the lower centroids along `axis`
+    int axis = -1;             // split axis (-1: the range was halved without looking at positions)
     int first = 0, count = 0;  // triangle range in the permuted order (leaf)
     int depth = 0;
 };
@@ -66,13 +67,13 @@ struct Builder {
             nodes[id].count = count;
             return id;
         }
-        int mid = split(first, count, box, cbox);
+        int axis = -1;
+        int mid = split(first, count, box, cbox, &axis);
         int l = build(first, mid - first, depth + 1);
         int r = build(mid, first + count - mid, depth + 1);
-        // fixed visiting order of the stackless walk: the child with the larger surface first
-        if (nodes[r].box.area() > nodes[l].box.area()) std::swap(l, r);
         nodes[id].left = l;
         nodes[id].right = r;
+        nodes[id].axis = axis;
         return id;
     }
 
@@ -126,9 +127,10 @@ struct Builder {
         return *best_axis >= 0;
     }
 
-    int split(int first, int count, const Box &box, const Box &cbox) {
+    int split(int first, int count, const Box &box, const Box &cbox, int *split_axis) {
         float cost;
         int axis, bin;
+        *split_axis = -1;
         if (best_split(first, count, box, cbox, &cost, &axis, &bin)) {
             float ext = cbox.mx[axis] - cbox.mn[axis];
             float scale = (float)BINS / ext;
@@ -137,7 +139,7 @@ struct Builder {
                 return b <= bin;
             });
             int mid = (int)(it - order.begin());
-            if (mid > first && mid < first + count) return mid;
+            if (mid > first && mid < first + count) { *split_axis = axis; return mid; }
         }
         // all centroids coincide (or a degenerate box): halve the range in its current order
         return first + count / 2;
@@ -152,10 +154,11 @@ inline float int_bits(int v) {
 
 } // namespace
 
-void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, BvhBuild *out) {
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, BvhBuild *out) {
     out->nodes.clear();
     out->tris.clear();
     out->n_nodes = out->n_top = out->max_depth = 0;
+    out->n_orders = 1;
     if (n_tri <= 0) return;
 
     Builder b;
@@ -186,7 +189,15 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
     int root = b.build(0, n_tri, 0);
     const int nn = (int)b.nodes.size();
 
-    // numbering: breadth-first for the first max_top nodes, depth-first (visiting order) for the rest
+    // Which child a ray of direction-sign class `order` looks at first.  Classes 0..7 are the sign octants (bit a set:
+    // the direction's component a is negative): the child on the side the ray comes from goes first, so that a hit
+    // found there culls the other child.  Class 8 ignores the direction: the child with the larger surface first.
+    auto first_child_is_left = [&](const TmpNode &nd, int order) {
+        if (order < 8 && nd.axis >= 0) return ((order >> nd.axis) & 1) == 0;
+        return b.nodes[nd.left].box.area() >= b.nodes[nd.right].box.area();
+    };
+
+    // numbering (the same for every order): breadth-first for the first max_top nodes, depth-first for the rest
     std::vector<int> index(nn, -1);
     int next_index = 0;
     {
@@ -197,8 +208,9 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             q.pop_front();
             index[id] = next_index++;
             if (b.nodes[id].left >= 0) {
-                q.push_back(b.nodes[id].left);
-                q.push_back(b.nodes[id].right);
+                const bool lf = first_child_is_left(b.nodes[id], 8);
+                q.push_back(lf ? b.nodes[id].left : b.nodes[id].right);
+                q.push_back(lf ? b.nodes[id].right : b.nodes[id].left);
             }
         }
     }
@@ -211,30 +223,40 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             stack.pop_back();
             if (index[id] < 0) index[id] = next_index++;
             if (b.nodes[id].left >= 0) {
-                stack.push_back(b.nodes[id].right);
-                stack.push_back(b.nodes[id].left);
+                const bool lf = first_child_is_left(b.nodes[id], 8);
+                stack.push_back(lf ? b.nodes[id].right : b.nodes[id].left);
+                stack.push_back(lf ? b.nodes[id].left : b.nodes[id].right);
             }
         }
     }
 
-    // threading: miss(node) = first node of whatever follows the node's subtree in visiting order
-    out->nodes.assign(8 * (size_t)nn, 0.0f);
+    // threading, once per order: miss(node) = first node of whatever follows the node's subtree in visiting order
+    out->n_orders = ordered ? 8 : 1;
+    out->nodes.assign(8 * (size_t)nn * (size_t)out->n_orders, 0.0f);
     struct Item { int id, next; };
     std::vector<Item> stack;
-    stack.push_back({root, -1});
-    while (!stack.empty()) {
-        Item it = stack.back();
-        stack.pop_back();
-        const TmpNode &nd = b.nodes[it.id];
-        float *dst = &out->nodes[8 * (size_t)index[it.id]];
-        for (int a = 0; a < 3; a++) { dst[a] = nd.box.mn[a]; dst[4 + a] = nd.box.mx[a]; }
-        dst[7] = int_bits(it.next);
-        if (nd.left >= 0) {
-            dst[3] = int_bits(index[nd.left]);
-            stack.push_back({nd.left, index[nd.right]});
-            stack.push_back({nd.right, it.next});
-        } else {
-            dst[3] = int_bits(~(nd.first * 8 + (nd.count - 1)));
+    for (int k = 0; k < out->n_orders; k++) {
+        const int order = ordered ? k : 8;
+        float *base = &out->nodes[8 * (size_t)nn * (size_t)k];
+        stack.push_back({root, -1});
+        while (!stack.empty()) {
+            Item it = stack.back();
+            stack.pop_back();
+            const TmpNode &nd = b.nodes[it.id];
+            float *dst = base + 8 * (size_t)index[it.id];
+            dst[0] = nd.box.mn[0]; dst[1] = nd.box.mx[0];
+            dst[2] = nd.box.mn[1]; dst[3] = nd.box.mx[1];
+            dst[4] = nd.box.mn[2]; dst[5] = nd.box.mx[2];
+            dst[7] = int_bits(it.next);
+            if (nd.left >= 0) {
+                const bool lf = first_child_is_left(nd, order);
+                const int c0 = lf ? nd.left : nd.right, c1 = lf ? nd.right : nd.left;
+                dst[6] = int_bits(index[c0]);
+                stack.push_back({c0, index[c1]});
+                stack.push_back({c1, it.next});
+            } else {
+                dst[6] = int_bits(~(nd.first * 8 + (nd.count - 1)));
+            }
         }
     }
 

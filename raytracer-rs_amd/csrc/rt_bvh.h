@@ -3,8 +3,12 @@
 // Takes the place of BVHTree::build_tree (src/mesh.rs:225-261) for ALL triangles of the world at once.  The
 // reference splits at the median of a random axis with one face per leaf; here the split is chosen by a binned
 // surface-area heuristic, leaves hold up to 4 faces, and the tree is laid out for a stack-free walk: every node
-// carries the index to continue with after a miss.  Only the set of triangles matters for results (the kernels apply
-// the reference's tie rule themselves), so the tree shape is free.
+// carries the index to continue with after a hit (its first child) and after a miss.  Only the set of triangles
+// matters for results (the kernels apply the reference's tie rule themselves), so the tree shape is free.
+//
+// A stack-free walk visits children in a fixed order.  To still look at the nearer child first, the links are written
+// once per sign octant of the ray direction (8 copies of the node array, same node numbering in each): a ray picks
+// the copy of its octant and then walks front to back along every split axis.
 #pragma once
 
 #include <cstdint>
@@ -13,14 +17,16 @@
 namespace rtd {
 
 struct BvhBuild {
-    std::vector<float> nodes; // 8 floats per node: bmin.xyz, link, bmax.xyz, miss (links stored as int bits)
+    std::vector<float> nodes; // n_orders arrays of n_nodes nodes, 8 floats each: xmin, xmax, ymin, ymax, zmin, zmax, link, miss (int bits);
+                              // link >= 0: first child, link < 0: ~(first_triangle * 8 + count - 1); miss: next node, -1 = walk finished
     std::vector<float> tris;  // 12 floats per triangle in leaf order: v0.xyz, prim, e1.xyz, mat, e2.xyz, 0
     int n_nodes = 0;
+    int n_orders = 1;         // 8: one node array per direction octant (bit a set = component a negative); 1: direction-independent order
     int n_top = 0;            // nodes [0, n_top) are the breadth-first top of the tree
     int max_depth = 0;
 };
 
 // tri_v: 9 floats per triangle; prim_id / mat per triangle.  max_top bounds n_top.
-void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, BvhBuild *out);
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, BvhBuild *out);
 
 } // namespace rtd

@@ -110,10 +110,12 @@ struct DevLight {
     float bmin[3], bmax[3]; // polygon light: padded box of its faces, a conservative gate in front of the exact tests
 };
 
-// BVH node, 32 B: a = (bmin.xyz, link), b = (bmax.xyz, miss).  link >= 0: index of the first child (inner node);
-// link < 0: leaf holding triangles [first, first+count) with ~link = first*8 + (count-1).  miss = node to continue
-// with when the box is missed or the subtree/leaf is done (-1 = traversal finished).  Nodes [0, n_top) are the top of
-// the tree in breadth-first order (the part each workgroup keeps in LDS); the rest follow in depth-first order.
+// BVH node, 32 B: a = (xmin, xmax, ymin, ymax), b = (zmin, zmax, link, miss).  link >= 0: index of the first child
+// (inner node); link < 0: leaf holding triangles [first, first+count) with ~link = first*8 + (count-1).  miss = node to
+// continue with when the box is missed or the subtree/leaf is done (-1 = traversal finished).  Nodes [0, n_top) are the
+// top of the tree in breadth-first order (the part each workgroup keeps in LDS); the rest follow in depth-first order.
+// `nodes` holds n_orders copies of the array (1, or 8 = one per sign octant of the ray direction) that differ only in
+// link and miss, i.e. in the order children are visited.
 // Triangle, 48 B: (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, unused) with e1 = v1-v0, e2 = v2-v0.
 struct DevScene {
     const float4 *nodes;
@@ -125,7 +127,7 @@ struct DevScene {
     const rt_material *mats;
     const DevLight *lights;
     const float *ltris;     // 9 floats per light triangle
-    int32_t n_nodes, n_top, n_tri, n_sph, n_cyl, n_light;
+    int32_t n_nodes, n_top, n_orders, n_tri, n_sph, n_cyl, n_light;
     // Boxes around the big meshes.  A ray that touches one is expected to walk deep into the BVH ("heavy"), the others
     // only meet the few large triangles around them; the queues keep the two kinds apart so that the lanes of a wave
     // have similar trip counts.  Purely a scheduling hint: results do not depend on it.
@@ -278,33 +280,54 @@ __device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_
 }
 __device__ __forceinline__ float u2f(unsigned int v) { return __uint_as_float(v); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// bytes of LDS the top-of-tree cache takes, and its fill (every thread of the workgroup must call it)
+__host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (uint32_t)sc.n_orders * 32u; }
+template <int BLOCK_THREADS>
+__device__ __forceinline__ void fill_top_cache(const DevScene &sc, float4 *lds_nodes) {
+    const int per = 2 * sc.n_top;
+    for (int k = 0; k < sc.n_orders; k++)
+        for (int j = threadIdx.x; j < per; j += BLOCK_THREADS) lds_nodes[k * per + j] = sc.nodes[(size_t)k * 2u * (size_t)sc.n_nodes + j];
+    __syncthreads();
+}
+
+// One box test per visited node, 3 packed multiply-adds for the six plane distances: t = plane * (1/d) - o * (1/d).
+// A component of d that is zero (or so small that the products overflow) turns that axis' distances into NaN or
+// infinities; min/max drop NaN operands, so such an axis never culls.
 template <bool ANY_HIT, bool COUNT, bool USE_LDS = false>
 __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     TriHit best{t_max, -1, -1};
     if (sc.n_nodes == 0) return best;
-    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * 32u);
+    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 32u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
+    const f32x2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+    const f32x2 ox2 = {-o.x * ix, -o.x * ix}, oy2 = {-o.y * iy, -o.y * iy}, oz2 = {-o.z * iz, -o.z * iz};
+    // the copy of the node array whose visiting order suits this ray's direction octant
+    const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
+    const uint32_t g_base = octant * (uint32_t)sc.n_nodes * 32u;
+    const float4 *l_base = lds_nodes + octant * (uint32_t)sc.n_top * 2u;
     int node = 0;
     while (node >= 0) {
         u32x4 na, nb;
         if (USE_LDS && node < sc.n_top) {
-            const float4 fa = lds_nodes[2 * node], fb = lds_nodes[2 * node + 1];
+            const float4 fa = l_base[2 * node], fb = l_base[2 * node + 1];
             na = u32x4{__float_as_uint(fa.x), __float_as_uint(fa.y), __float_as_uint(fa.z), __float_as_uint(fa.w)};
             nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fb.z), __float_as_uint(fb.w)};
         } else {
-            na = load16(node_r, (uint32_t)node * 32u);
-            nb = load16(node_r, (uint32_t)node * 32u + 16u);
+            na = load16(node_r, g_base + (uint32_t)node * 32u);
+            nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);
         }
         if (COUNT) (*n_nodes)++;
-        const float x0 = (u2f(na.x) - o.x) * ix, x1 = (u2f(nb.x) - o.x) * ix;
-        const float y0 = (u2f(na.y) - o.y) * iy, y1 = (u2f(nb.y) - o.y) * iy;
-        const float z0 = (u2f(na.z) - o.z) * iz, z1 = (u2f(nb.z) - o.z) * iz;
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
-        const bool inside = tn <= tf * 1.00001f + 1e-7f;
-        const int link = (int)na.w, miss = (int)nb.w;
+        const f32x2 tx = __builtin_elementwise_fma(f32x2{u2f(na.x), u2f(na.y)}, ix2, ox2);
+        const f32x2 ty = __builtin_elementwise_fma(f32x2{u2f(na.z), u2f(na.w)}, iy2, oy2);
+        const f32x2 tz = __builtin_elementwise_fma(f32x2{u2f(nb.x), u2f(nb.y)}, iz2, oz2);
+        const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
+        const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), best.t));
+        const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
+        const int link = (int)nb.z, miss = (int)nb.w;
         node = (inside && link >= 0) ? link : miss;
         if (inside && link < 0) {
             const int packed = ~link;

@@ -12,7 +12,6 @@
 // Built with -ffp-contract=off: see rt_device.h.
 
 #include "rt_kernels.h"
-#include "rt_trace.h"
 
 namespace rtd {
 
@@ -75,10 +74,6 @@ __device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)
 }
 
 __device__ __forceinline__ void add_pixel(float *planes, uint32_t n_pixels, uint32_t pixel, F3 c) {
-#ifdef RT_EXPERIMENT_NO_ACCUM
-    if (c.x == 12345.678f) planes[0] = c.y; // keep the operands alive, add nothing
-    return;
-#endif
     atomicAdd(planes + pixel, c.x);
     atomicAdd(planes + n_pixels + pixel, c.y);
     atomicAdd(planes + 2u * n_pixels + pixel, c.z);
@@ -227,15 +222,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     if (bx * BLOCK >= n_seg) return;
-    if (USE_LDS) {
-        for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-        __syncthreads();
-    }
     const uint32_t il = bx * BLOCK + threadIdx.x;
-    if (il >= n_seg) return;
     const uint32_t i = seg * seg_capacity + il;
-    float4 a = in.a[i], b = in.b[i];
-    F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
+    // the ray's loads are in flight while the top of the tree is copied into LDS
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (il < n_seg) { a = in.a[i]; b = in.b[i]; }
+    if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+    if (il >= n_seg) return;
+    const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     float t_obj;
     int code, prim;
     uint32_t nn = 0, nt = 0;
@@ -244,27 +238,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
         atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+        atomicAdd(&ctl->h.hist_ray[min(15, 32 - __clz((int)nn))], 1ull);
+        uint32_t wmax = nn;
+        for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
+        if (__ffsll(__ballot(1)) - 1 == (int)(threadIdx.x & 63u)) {
+            atomicAdd(&ctl->h.hist_wave[min(15, 32 - __clz((int)wmax))], 1ull);
+            atomicAdd(&ctl->h.wave_steps, (unsigned long long)wmax);
+        }
     }
-}
-
-// ---- persistent traversal kernels (rt_trace.h) -------------------------------------------------------------------
-template <bool COUNT, int REFILL, int LEAF_T>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_closest(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity) {
-    extern __shared__ float4 lds_nodes[];
-    __shared__ int chunk_prefix[RT_NSEG + 1];
-    __shared__ uint32_t seg_count[RT_NSEG];
-    trace_persistent<false, COUNT, REFILL, LEAF_T>(sc, rc, ctl, &ctl->seg_in[0].v, (uint32_t)(sizeof(SegCounter) / sizeof(uint32_t)), seg_capacity, in.a, in.b,
-                                                   nullptr, hit, nullptr, 0u, lds_nodes, chunk_prefix, seg_count);
-}
-
-template <bool COUNT, int REFILL, int LEAF_T>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                                                              uint32_t shadow_seg_capacity) {
-    extern __shared__ float4 lds_nodes[];
-    __shared__ int chunk_prefix[RT_NSEG + 1];
-    __shared__ uint32_t seg_count[RT_NSEG];
-    trace_persistent<true, COUNT, REFILL, LEAF_T>(sc, rc, ctl, ctl->seg_shadow_cur, 1u, shadow_seg_capacity, sh.a, sh.b, sh.c, nullptr, planes, n_pixels,
-                                                  lds_nodes, chunk_prefix, seg_count);
 }
 
 // ---- surface point ---------------------------------------------------------------------------------------------------
@@ -593,16 +574,14 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
     const uint32_t n = min(ctl->seg_shadow_cur[seg], shadow_seg_capacity);
     if (bx * BLOCK >= n) return;
-    if (USE_LDS) {
-        for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-        __syncthreads();
-    }
     const uint32_t il = bx * BLOCK + threadIdx.x;
-    if (il >= n) return;
     const uint32_t i = seg * shadow_seg_capacity + il;
-    float4 a = sh.a[i], b = sh.b[i];
-    float2 c = sh.c[i];
-    F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    float2 c = make_float2(0, 0);
+    if (il < n) { a = sh.a[i]; b = sh.b[i]; c = sh.c[i]; }
+    if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+    if (il >= n) return;
+    const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     uint32_t nn = 0, nt = 0;
     bool occ = world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
@@ -614,9 +593,6 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
 
 // ---- normal shader (shader.rs:7-13): no queues, one thread per pixel looping over its samples ---------------------------
 __global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderConst rc, float *planes, uint32_t n_pixels) {
-    extern __shared__ float4 lds_nodes[];
-    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-    __syncthreads();
     const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
     if (pixel >= n_pixels) return;
     int x = (int)(pixel % (uint32_t)rc.width), y = (int)(pixel / (uint32_t)rc.width);
@@ -629,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderCons
         float t;
         int code, prim;
         uint32_t nn, nt;
-        world_hit<false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t, &code, &prim, &nn, &nt);
+        world_hit<false>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t, &code, &prim, &nn, &nt);
         if (code != HIT_NONE) {
             F3 n;
             int mat;
@@ -647,9 +623,6 @@ __global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderCons
 
 // ---- primary-hit AOV -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_primary_hits(DevScene sc, RenderConst rc, int32_t *prim_out, float *t_out) {
-    extern __shared__ float4 lds_nodes[];
-    for (int j = threadIdx.x; j < 2 * sc.n_top; j += BLOCK) lds_nodes[j] = sc.nodes[j];
-    __syncthreads();
     const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
     if (pixel >= (uint32_t)(rc.width * rc.height)) return;
     int x = (int)(pixel % (uint32_t)rc.width), y = (int)(pixel / (uint32_t)rc.width);
@@ -661,7 +634,7 @@ __global__ __launch_bounds__(BLOCK) void k_primary_hits(DevScene sc, RenderConst
             int code, pr;
             uint32_t nn, nt;
             float th;
-            world_hit<false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &th, &code, &pr, &nn, &nt);
+            world_hit<false>(sc, nullptr, o, d, rc.t_min, rc.t_max, &th, &code, &pr, &nn, &nt);
             if (code != HIT_NONE) { prim = pr; t = th; }
         }
     }
@@ -691,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long 
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
-static inline size_t lds_bytes(const DevScene &sc) { return (size_t)sc.n_top * 2 * sizeof(float4); }
+static inline size_t lds_bytes(const DevScene &sc) { return top_cache_bytes(sc); }
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
 
@@ -699,25 +672,6 @@ void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
                    uint32_t n_threads) {
     if (!n_threads) return;
     hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, sc, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
-}
-
-// workgroups of a persistent kernel that are resident at once (they split the queue statically, so all must run together)
-template <class K> static uint32_t resident_blocks(K kernel, size_t lds) {
-    int dev = 0, cus = 0, per_cu = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TRACE_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    return (uint32_t)(cus > 0 ? cus : 256) * (uint32_t)per_cu;
-}
-
-static int trace_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("RT_TRACE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
 }
 
 static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads, uint32_t *heavy_blocks) {
@@ -730,26 +684,10 @@ void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     uint32_t hb;
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
-    const int variant = trace_variant();
-    if (variant == 0) { // one ray per lane for the lifetime of the wave
-        dim3 g(grid), b(BLOCK);
-        if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-        else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-        else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-        return;
-    }
-    const uint32_t want = grid;
-#define TRACE_LAUNCH(K)                                                                                                   \
-    do {                                                                                                                  \
-        static uint32_t res = 0;                                                                                          \
-        if (!res) res = resident_blocks(K, lds_bytes(sc));                                                                \
-        hipLaunchKernelGGL(K, dim3(want < res ? want : res), dim3(TRACE_BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity); \
-    } while (0)
-    if (count) TRACE_LAUNCH((k_trace_closest<true, 24, 16>));
-    else if (variant == 1) TRACE_LAUNCH((k_trace_closest<false, 16, 8>));
-    else if (variant == 2) TRACE_LAUNCH((k_trace_closest<false, 24, 16>));
-    else TRACE_LAUNCH((k_trace_closest<false, 24, 1>));
-#undef TRACE_LAUNCH
+    dim3 g(grid), b(BLOCK);
+    if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
@@ -771,36 +709,19 @@ void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     uint32_t hb;
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
-    const int variant = trace_variant();
-    if (variant == 0) {
-        dim3 g(grid), b(BLOCK);
-        if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-        else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-        else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-        return;
-    }
-    const uint32_t want = grid;
-#define TRACE_LAUNCH(K)                                                                                                   \
-    do {                                                                                                                  \
-        static uint32_t res = 0;                                                                                          \
-        if (!res) res = resident_blocks(K, lds_bytes(sc));                                                                \
-        hipLaunchKernelGGL(K, dim3(want < res ? want : res), dim3(TRACE_BLOCK), lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, \
-                           cfg.shadow_seg_capacity);                                                                      \
-    } while (0)
-    if (count) TRACE_LAUNCH((k_trace_shadow<true, 24, 16>));
-    else if (variant == 1) TRACE_LAUNCH((k_trace_shadow<false, 16, 8>));
-    else if (variant == 2) TRACE_LAUNCH((k_trace_shadow<false, 24, 16>));
-    else TRACE_LAUNCH((k_trace_shadow<false, 24, 1>));
-#undef TRACE_LAUNCH
+    dim3 g(grid), b(BLOCK);
+    if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
 }
 
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels) {
-    hipLaunchKernelGGL(k_normal_shader, dim3(nblocks(n_pixels)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, planes, n_pixels);
+    hipLaunchKernelGGL(k_normal_shader, dim3(nblocks(n_pixels)), dim3(BLOCK), 0, cfg.stream, sc, rc, planes, n_pixels);
 }
 
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t) {
     uint32_t n = (uint32_t)(rc.width * rc.height);
-    hipLaunchKernelGGL(k_primary_hits, dim3(nblocks(n)), dim3(BLOCK), lds_bytes(sc), cfg.stream, sc, rc, prim, t);
+    hipLaunchKernelGGL(k_primary_hits, dim3(nblocks(n)), dim3(BLOCK), 0, cfg.stream, sc, rc, prim, t);
 }
 
 void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const float *planes, float *accum_rgb, uint32_t n_pixels) {

@@ -1,0 +1,7 @@
+#!/bin/bash
+# ab.sh WORKLOAD SPP LIB...: parity quick check and bench stage split for each exp/LIB.so (run on the GPU box)
+wl=$1; spp=$2; shift 2
+for v in "$@"; do
+  echo "== $v"
+  RT_HIP_LIB=exp/$v.so timeout -k 10 200 python3 bench.py --workload $wl --spp $spp --steps 2 --warmup 1 --no-cpu-baseline --no-count-pass 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['config']['stage_ms_per_step_rank0'])" || exit 1
+done

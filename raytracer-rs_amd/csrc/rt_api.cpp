@@ -73,10 +73,12 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
 struct rt_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // occlusion queries of the previous iteration run here, beside the next iteration's extend/shade
+    hipEvent_t shadow_done = nullptr;
     // queue pool, sized on demand
     uint32_t capacity = 0, shadow_capacity = 0;
-    DevBuf<float4> qa[2], qb[2], qc[2], hit, sa, sb;
-    DevBuf<float2> sc2;
+    DevBuf<float4> qa[2], qb[2], qc[2], hit, sa[2], sb[2];
+    DevBuf<float2> sc2[2];
     DevBuf<float> planes, accum_tmp;
     DevBuf<int32_t> blocks, prim_tmp;
     DevBuf<float> t_tmp;
@@ -174,9 +176,11 @@ int ensure_queues(rt_context *ctx, uint32_t capacity, uint32_t shadow_capacity, 
         ctx->capacity = capacity;
     }
     if (shadow_capacity > ctx->shadow_capacity) {
-        HIP_TRY(ctx->sa.ensure(shadow_capacity));
-        HIP_TRY(ctx->sb.ensure(shadow_capacity));
-        HIP_TRY(ctx->sc2.ensure(shadow_capacity));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(ctx->sa[k].ensure(shadow_capacity));
+            HIP_TRY(ctx->sb[k].ensure(shadow_capacity));
+            HIP_TRY(ctx->sc2[k].ensure(shadow_capacity));
+        }
         ctx->shadow_capacity = shadow_capacity;
     }
     HIP_TRY(ctx->planes.ensure(3 * n_pixels));
@@ -198,14 +202,16 @@ struct StageTimer {
         }
         return ctx->events[used++];
     }
-    void begin(int stage) {
+    hipStream_t cur_stream = nullptr;
+    void begin(int stage, hipStream_t stream = nullptr) {
         if (!on) return;
+        cur_stream = stream ? stream : ctx->stream;
         spans.push_back({stage, used});
-        (void)hipEventRecord(get(), ctx->stream);
+        (void)hipEventRecord(get(), cur_stream);
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(get(), ctx->stream);
+        (void)hipEventRecord(get(), cur_stream);
     }
     // call after a stream synchronisation
     void collect() {
@@ -248,6 +254,8 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->shadow_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -263,11 +271,14 @@ int32_t rt_context_destroy(rt_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 2; k++) { ctx->qa[k].release(); ctx->qb[k].release(); ctx->qc[k].release(); }
-    ctx->hit.release(); ctx->sa.release(); ctx->sb.release(); ctx->sc2.release();
+    ctx->hit.release();
+    for (int k = 0; k < 2; k++) { ctx->sa[k].release(); ctx->sb[k].release(); ctx->sc2[k].release(); }
     ctx->planes.release(); ctx->accum_tmp.release(); ctx->blocks.release(); ctx->prim_tmp.release(); ctx->t_tmp.release();
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->ctl) (void)hipFree(ctx->ctl);
     if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
+    if (ctx->shadow_done) (void)hipEventDestroy(ctx->shadow_done);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -529,9 +540,15 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         ctx->ctl_host->per_sample = n_blocks * 64u;
         HIP_TRY(hipMemcpyAsync(&ctx->ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        int cur = 0;
-        ShadowQueue sh{ctx->sa.p, ctx->sb.p, ctx->sc2.p};
+        int cur = 0, scur = 0;
+        // The occlusion queries an iteration's shading queues are traced during the NEXT iteration, on a second stream
+        // beside that iteration's ray generation, extend and shade (which fill the other shadow buffer).
+        const bool overlap = env_u32_allow_zero("RT_OVERLAP", 1) != 0;
+        hipStream_t shadow_stream = overlap ? ctx->stream2 : ctx->stream;
+        bool shadow_pending = false;
         for (;;) {
+            if (shadow_pending && overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->shadow_done, 0)); // k_plan rewrites the counts k_shadow reads
+            shadow_pending = false;
             launch_plan(cfg, ctx->ctl);
             HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &ctx->ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -540,15 +557,21 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
             // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
             if (c.max_sh_light || c.max_sh_heavy) {
-                timer.begin(2);
-                launch_shadow(cfg, s->dev, rcst, ctx->ctl, sh, ctx->planes.p, (uint32_t)plane_stride, std::min(c.max_sh_light, shadow_seg_capacity),
+                ShadowQueue filled{ctx->sa[scur ^ 1].p, ctx->sb[scur ^ 1].p, ctx->sc2[scur ^ 1].p};
+                LaunchCfg scfg = cfg;
+                scfg.stream = shadow_stream;
+                timer.begin(2, shadow_stream);
+                launch_shadow(scfg, s->dev, rcst, ctx->ctl, filled, ctx->planes.p, (uint32_t)plane_stride, std::min(c.max_sh_light, shadow_seg_capacity),
                               std::min(c.max_sh_heavy, shadow_seg_capacity), count_work);
                 timer.end();
+                if (overlap) HIP_TRY(hipEventRecord(ctx->shadow_done, shadow_stream));
+                shadow_pending = true;
                 st.launches_shadow++;
             }
             if (c.done) break;
             NodeQueue in{ctx->qa[cur].p, ctx->qb[cur].p, ctx->qc[cur].p};
             NodeQueue out{ctx->qa[cur ^ 1].p, ctx->qb[cur ^ 1].p, ctx->qc[cur ^ 1].p};
+            ShadowQueue sh{ctx->sa[scur].p, ctx->sb[scur].p, ctx->sc2[scur].p};
             if (c.n_new) {
                 timer.begin(3);
                 launch_raygen(cfg, s->dev, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
@@ -572,7 +595,9 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
             cur ^= 1;
+            scur ^= 1;
         }
+        if (overlap) HIP_TRY(hipStreamSynchronize(ctx->stream2));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         timer.collect();
         const CtlHead c = *ctx->ctl_host;

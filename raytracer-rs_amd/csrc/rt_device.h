@@ -282,13 +282,25 @@ __device__ __forceinline__ float u2f(unsigned int v) { return __uint_as_float(v)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// bytes of LDS the top-of-tree cache takes, and its fill (every thread of the workgroup must call it)
-__host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (uint32_t)sc.n_orders * 32u; }
+// Top-of-tree cache in LDS.  The boxes are the same in every visiting order, so they are kept once; only the
+// (link, miss) pairs are kept per order: [n_top x float4 (xmin,xmax,ymin,ymax)][n_top x float2 (zmin,zmax)]
+// [n_orders x n_top x int2 (link, miss)] = 24 + 8 * n_orders bytes per node.
+__host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (24u + 8u * (uint32_t)sc.n_orders); }
+// every thread of the workgroup must call it
 template <int BLOCK_THREADS>
 __device__ __forceinline__ void fill_top_cache(const DevScene &sc, float4 *lds_nodes) {
-    const int per = 2 * sc.n_top;
-    for (int k = 0; k < sc.n_orders; k++)
-        for (int j = threadIdx.x; j < per; j += BLOCK_THREADS) lds_nodes[k * per + j] = sc.nodes[(size_t)k * 2u * (size_t)sc.n_nodes + j];
+    float2 *box_b = reinterpret_cast<float2 *>(lds_nodes + sc.n_top);
+    float2 *links = box_b + sc.n_top;
+    for (int j = threadIdx.x; j < sc.n_top; j += BLOCK_THREADS) {
+        const float4 b = sc.nodes[2 * j + 1];
+        lds_nodes[j] = sc.nodes[2 * j];
+        box_b[j] = make_float2(b.x, b.y);
+    }
+    for (int j = threadIdx.x; j < sc.n_top * sc.n_orders; j += BLOCK_THREADS) {
+        const int k = j / sc.n_top, node = j - k * sc.n_top;
+        const float4 b = sc.nodes[2u * ((size_t)k * (size_t)sc.n_nodes + (size_t)node) + 1u];
+        links[j] = make_float2(b.z, b.w);
+    }
     __syncthreads();
 }
 
@@ -308,14 +320,16 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
     // the copy of the node array whose visiting order suits this ray's direction octant
     const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
     const uint32_t g_base = octant * (uint32_t)sc.n_nodes * 32u;
-    const float4 *l_base = lds_nodes + octant * (uint32_t)sc.n_top * 2u;
+    const float2 *l_box_b = reinterpret_cast<const float2 *>(lds_nodes + sc.n_top);
+    const float2 *l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
     int node = 0;
     while (node >= 0) {
         u32x4 na, nb;
         if (USE_LDS && node < sc.n_top) {
-            const float4 fa = l_base[2 * node], fb = l_base[2 * node + 1];
+            const float4 fa = lds_nodes[node];
+            const float2 fb = l_box_b[node], fl = l_links[node];
             na = u32x4{__float_as_uint(fa.x), __float_as_uint(fa.y), __float_as_uint(fa.z), __float_as_uint(fa.w)};
-            nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fb.z), __float_as_uint(fb.w)};
+            nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fl.x), __float_as_uint(fl.y)};
         } else {
             na = load16(node_r, g_base + (uint32_t)node * 32u);
             nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);

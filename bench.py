@@ -172,7 +172,12 @@ def main() -> int:
             dom = max(kernels.values(), key=lambda k: k["ms_per_step"])
             roofline = dict(dom)
             roofline["note"] = ("HBM roofline of the kernel with the largest share of the step; traversal kernels are bound by divergence and "
-                                "L1/L2 latency, not HBM: BVH/triangle fetches (cache_bytes_per_ray) never leave the caches")
+                                "L1/L2 latency, not HBM: BVH/triangle fetches (cache_bytes_per_ray) never leave the caches.  k_shadow of one "
+                                "iteration runs on a second stream beside k_extend/k_shade of the next, so the kernels' durations overlap "
+                                "(their sum exceeds the step) and each includes the slowdown from sharing the GPU")
+            total_bytes = sum(units * bpu for units, bpu, _, _ in per_unit.values()) / steps
+            roofline["whole_step"] = {"algorithmic_bytes": round(total_bytes), "achieved": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                      "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 4), "unit": "GB/s"}
             roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)
             roofline["nodes_per_ray"] = round(nodes_per_ray, 2)
             roofline["tris_per_ray"] = round(tris_per_ray, 2)

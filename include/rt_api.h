@@ -184,6 +184,18 @@ void *rt_context_stream(rt_context *ctx);
  * (= white, see sampler.rs:243-250) pixel sampler, whole frame, all samples. */
 void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp);
 
+/* Host-only diagnostic (no GPU needed): builds the acceleration structure rt_scene_create builds for the given
+ * triangles (9 floats each; primitive id = position in the list) and copies it out.  Takes the place of
+ * BVHTree::build_tree (src/mesh.rs:225-261).  Layout: `ordered` != 0 gives 8 node arrays, one per sign octant of the
+ * ray direction (bit a of the array index set = component a negative), else 1; each array has *n_nodes nodes of 8
+ * floats: xmin, xmax, ymin, ymax, zmin, zmax, link, miss (the last two are int32 bit patterns).  link >= 0: node to
+ * continue with when the box is hit; link < 0: leaf with triangles [first, first + count), ~link = first * 8 + count - 1.
+ * miss: node to continue with when the box is missed or the leaf is done, -1 = walk finished.  Triangles are written
+ * in leaf order, 12 floats each: v0.xyz, primitive id (int32 bits), v1 - v0, material (int32 bits, 0 here), v2 - v0, 0.
+ * nodes_out / tris_out may be NULL (sizes only); they must hold n_orders * n_nodes * 8 and n_tri * 12 floats. */
+int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, int32_t ordered, float *nodes_out, float *tris_out,
+                          int32_t *n_nodes, int32_t *n_top, int32_t *n_orders);
+
 #ifdef __cplusplus
 }
 #endif

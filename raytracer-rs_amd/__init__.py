@@ -308,8 +308,26 @@ def hip_lib() -> C.CDLL:
         lib.rt_context_stream.restype = C.c_void_p
         lib.rt_params_default.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32]
         lib.rt_params_default.restype = None
+        lib.rt_bvh_build_host.argtypes = [c_float_p, C.c_int32, C.c_int32, C.c_int32, c_float_p, c_float_p, c_int32_p, c_int32_p, c_int32_p]
+        lib.rt_bvh_build_host.restype = C.c_int32
         _hip = lib
     return _hip
+
+
+def bvh_build_host(tri_v: np.ndarray, max_top: int = 32, ordered: bool = True):
+    """rt_bvh_build_host: the device library's BVH for `tri_v` ((n, 9) float32), built on the host (no GPU needed).
+
+    Returns (nodes, tris, n_top): nodes is (n_orders, n_nodes, 8) float32 with columns xmin, xmax, ymin, ymax, zmin,
+    zmax, link, miss (the last two int32 bit patterns), tris is (n, 12) float32 in leaf order."""
+    tri_v = np.ascontiguousarray(tri_v, np.float32).reshape(-1, 9)
+    n = tri_v.shape[0]
+    nn, nt, no = C.c_int32(), C.c_int32(), C.c_int32()
+    lib = hip_lib()
+    _check(lib.rt_bvh_build_host(_fp(tri_v), n, max_top, int(ordered), None, None, C.byref(nn), C.byref(nt), C.byref(no)))
+    nodes = np.zeros((no.value, nn.value, 8), np.float32)
+    tris = np.zeros((n, 12), np.float32)
+    _check(lib.rt_bvh_build_host(_fp(tri_v), n, max_top, int(ordered), _fp(nodes), _fp(tris), C.byref(nn), C.byref(nt), C.byref(no)))
+    return nodes, tris, nt.value
 
 
 def _check(rc: int):

@@ -231,6 +231,21 @@ extern "C" {
 
 const char *rt_last_error(void) { return g_err.c_str(); }
 
+int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, int32_t ordered, float *nodes_out, float *tris_out, int32_t *n_nodes,
+                          int32_t *n_top, int32_t *n_orders) {
+    if (n_tri < 0 || (n_tri > 0 && !tri_v) || max_top < 0) return fail(RT_ERR_INVALID, "rt_bvh_build_host: bad arguments");
+    std::vector<int32_t> prim((size_t)n_tri), mat((size_t)n_tri, 0);
+    for (int i = 0; i < n_tri; i++) prim[(size_t)i] = i;
+    BvhBuild b;
+    build_bvh(tri_v, prim.data(), mat.data(), n_tri, max_top, ordered != 0, &b);
+    if (n_nodes) *n_nodes = b.n_nodes;
+    if (n_top) *n_top = b.n_top;
+    if (n_orders) *n_orders = b.n_orders;
+    if (nodes_out && !b.nodes.empty()) std::memcpy(nodes_out, b.nodes.data(), b.nodes.size() * sizeof(float));
+    if (tris_out && !b.tris.empty()) std::memcpy(tris_out, b.tris.data(), b.tris.size() * sizeof(float));
+    return RT_OK;
+}
+
 void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp) {
     std::memset(p, 0, sizeof(*p));
     p->width = width; p->height = height; p->spp = spp;

@@ -1,0 +1,164 @@
+"""The threaded BVH of the device library, built on the host and walked in numpy (no GPU needed).
+
+Checks the invariants the device kernels rely on: every triangle sits in exactly one leaf, every visiting order walks
+every node exactly once when nothing is culled, boxes contain their subtrees, and a stack-free walk with culling finds
+the same closest hit as a scan over all triangles (the reference's semantics, hitable.rs:35-62 + geometry.rs:29-63,
+later triangle wins at equal t) — for every one of the 8 direction orders, matching the ray's octant or not.
+"""
+import numpy as np
+import pytest
+
+F = np.float32
+
+
+def soup(n, seed, flat=False):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-10, 10, (n, 1, 3))
+    v = c + rng.uniform(-1.0, 1.0, (n, 3, 3))
+    if flat:  # axis-aligned, zero-thickness boxes
+        v[:, :, 1] = np.round(c[:, :, 1])
+    return v.astype(F).reshape(n, 9)
+
+
+def links(nodes):
+    return nodes[..., 6].view(np.int32), nodes[..., 7].view(np.int32)
+
+
+def tri_hit(v0, e1, e2, o, d, t_min, t_max):
+    """geometry.rs:29-63 in float32, back faces culled."""
+    P = np.cross(d, e2).astype(F)
+    det = F(np.dot(P, e1))
+    if det < 0 or det == 0:
+        return None
+    inv = F(1.0) / det
+    T = (o - v0).astype(F)
+    Q = np.cross(T, e1).astype(F)
+    u = F(inv * F(np.dot(P, T)))
+    if u < 0 or u > 1:
+        return None
+    v = F(inv * F(np.dot(Q, d)))
+    if v < 0 or F(u + v) > 1:
+        return None
+    t = F(inv * F(np.dot(Q, e2)))
+    if t < t_min or t > t_max:
+        return None
+    return t
+
+
+def brute(tris, o, d, t_min, t_max):
+    best_t, best_p = F(t_max), -1
+    for k in range(tris.shape[0]):
+        t = tri_hit(tris[k, 0:3], tris[k, 4:7], tris[k, 8:11], o, d, t_min, t_max)
+        if t is None:
+            continue
+        p = int(tris[k, 3:4].view(np.int32)[0])
+        if t < best_t or (t == best_t and p > best_p):
+            best_t, best_p = t, p
+    return best_t, best_p
+
+
+def walk(nodes, tris, o, d, t_min, t_max):
+    """The kernels' stack-free walk (one box test per node, culling against the closest hit so far)."""
+    link, miss = links(nodes)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = (F(1.0) / d).astype(F)
+        best_t, best_p, node, visited = F(t_max), -1, 0, 0
+        while node >= 0:
+            visited += 1
+            assert visited <= nodes.shape[0], "a walk never sees a node twice"
+            b = nodes[node]
+            t0 = ((b[[0, 2, 4]] - o) * inv).astype(F)
+            t1 = ((b[[1, 3, 5]] - o) * inv).astype(F)
+            tn = np.fmax(np.fmax.reduce(np.fmin(t0, t1)), F(t_min))
+            tf = np.fmin(np.fmin.reduce(np.fmax(t0, t1)), best_t)
+            inside = tn <= F(tf * F(1.00001) + F(1e-7))
+            lk = int(link[node])
+            if inside and lk < 0:
+                first, count = (~lk) >> 3, ((~lk) & 7) + 1
+                for k in range(first, first + count):
+                    t = tri_hit(tris[k, 0:3], tris[k, 4:7], tris[k, 8:11], o, d, t_min, t_max)
+                    if t is not None:
+                        p = int(tris[k, 3:4].view(np.int32)[0])
+                        if t < best_t or (t == best_t and p > best_p):
+                            best_t, best_p = t, p
+            node = lk if (inside and lk >= 0) else int(miss[node])
+    return best_t, best_p, visited
+
+
+@pytest.mark.parametrize("n,ordered", [(1, True), (2, False), (7, True), (200, True), (200, False), (1500, True)])
+def test_structure(rt, n, ordered):
+    tri_v = soup(n, n)
+    nodes, tris, n_top = rt.bvh_build_host(tri_v, max_top=16, ordered=ordered)
+    assert nodes.shape[0] == (8 if ordered else 1) and 1 <= nodes.shape[1] <= 2 * n - 1 and 1 <= n_top <= min(16, nodes.shape[1])
+    # triangles: a permutation of the input, edges precomputed
+    prim = tris[:, 3].view(np.int32)
+    assert sorted(prim.tolist()) == list(range(n))
+    assert np.array_equal(tris[:, 0:3], tri_v[prim, 0:3])
+    assert np.array_equal(tris[:, 4:7], tri_v[prim, 3:6] - tri_v[prim, 0:3])
+    assert np.array_equal(tris[:, 8:11], tri_v[prim, 6:9] - tri_v[prim, 0:3])
+    # the boxes are the same in every order
+    for k in range(1, nodes.shape[0]):
+        assert np.array_equal(nodes[k, :, :6], nodes[0, :, :6])
+    for k in range(nodes.shape[0]):
+        link, miss = links(nodes[k])
+        # following link at inner nodes and miss at leaves visits every node exactly once, every triangle exactly once
+        seen_nodes, seen_tris, node = [], [], 0
+        while node >= 0:
+            seen_nodes.append(node)
+            lk = int(link[node])
+            if lk < 0:
+                first, count = (~lk) >> 3, ((~lk) & 7) + 1
+                assert 1 <= count <= 4
+                seen_tris += list(range(first, first + count))
+                # the leaf's box contains its (padded) triangles
+                v = np.concatenate([tris[first:first + count, 0:3], tris[first:first + count, 0:3] + tris[first:first + count, 4:7],
+                                    tris[first:first + count, 0:3] + tris[first:first + count, 8:11]])
+                b = nodes[k, node]
+                assert (v.min(0) >= b[[0, 2, 4]]).all() and (v.max(0) <= b[[1, 3, 5]]).all()
+                node = int(miss[node])
+            else:
+                node = lk
+            assert len(seen_nodes) <= nodes.shape[1]
+        assert sorted(seen_nodes) == list(range(nodes.shape[1]))
+        assert sorted(seen_tris) == list(range(n))
+        # always taking miss from the root ends the walk at once; a child's box lies inside its parent's
+        assert miss[0] == -1
+        for node in range(nodes.shape[1]):
+            lk = int(link[node])
+            if lk >= 0:
+                sib = int(miss[lk])  # the second child is where the first child's subtree exits to
+                for c in (lk, sib):
+                    assert (nodes[k, c, [0, 2, 4]] >= nodes[k, node, [0, 2, 4]]).all() and (nodes[k, c, [1, 3, 5]] <= nodes[k, node, [1, 3, 5]]).all()
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_walk_matches_scan_in_every_order(rt, flat):
+    n = 300
+    tri_v = soup(n, 77, flat)
+    nodes, tris, _ = rt.bvh_build_host(tri_v, max_top=8, ordered=True)
+    rng = np.random.default_rng(5)
+    hits = 0
+    fewer = 0
+    for r in range(60):
+        o = rng.uniform(-14, 14, 3).astype(F)
+        tgt = tri_v[rng.integers(n)].reshape(3, 3).mean(0) + rng.normal(0, 0.1, 3)
+        d = (tgt - o).astype(F)
+        if r % 10 == 0:
+            d[r // 10 % 3] = F(0.0)  # a zero component: that axis' slab test degenerates
+        want = brute(tris, o, d, F(1e-3), F(1e7))
+        octant = int(d[0] < 0) | (int(d[1] < 0) << 1) | (int(d[2] < 0) << 2)
+        visited = {}
+        for k in (octant, octant ^ 7, (octant + 3) % 8):
+            t, p, visited[k] = walk(nodes[k], tris, o, d, F(1e-3), F(1e7))
+            assert (t, p) == want, (r, k)
+        hits += want[1] >= 0
+        fewer += visited[octant] <= visited[octant ^ 7]
+    assert hits >= 10
+    assert fewer > 40  # front-to-back order visits no more nodes than back-to-front for most rays
+
+
+def test_empty_and_argument_errors(rt):
+    nodes, tris, n_top = rt.bvh_build_host(np.zeros((0, 9), F))
+    assert nodes.shape[1] == 0 and tris.shape[0] == 0 and n_top == 0
+    with pytest.raises(rt.RtError):
+        rt.bvh_build_host(soup(3, 1), max_top=-1)

@@ -46,7 +46,7 @@ struct Builder {
     std::vector<TmpNode> nodes;
     int max_depth = 0;
 
-    static constexpr int MAX_LEAF = 4;
+    int max_leaf = 1; // measured on MI355X: one triangle per leaf beats 2 and 4 (a wave runs the triangle test of every leaf any of its lanes enters)
     static constexpr int BINS = 16;
 
     int build(int first, int count, int depth) {
@@ -62,7 +62,7 @@ struct Builder {
         }
         nodes[id].box = box;
         nodes[id].depth = depth;
-        if (count <= MAX_LEAF && (count == 1 || depth > 48 || !worth_splitting(first, count, box, cbox))) {
+        if (count <= max_leaf && (count == 1 || depth > 48 || !worth_splitting(first, count, box, cbox))) {
             nodes[id].first = first;
             nodes[id].count = count;
             return id;
@@ -154,7 +154,7 @@ inline float int_bits(int v) {
 
 } // namespace
 
-void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, BvhBuild *out) {
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, BvhBuild *out) {
     out->nodes.clear();
     out->tris.clear();
     out->n_nodes = out->n_top = out->max_depth = 0;
@@ -164,6 +164,7 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
     Builder b;
     b.tri_v = tri_v;
     b.n = n_tri;
+    b.max_leaf = std::min(4, std::max(1, max_leaf));
     b.tbox.resize(n_tri);
     b.centroid.resize(3 * (size_t)n_tri);
     b.order.resize(n_tri);

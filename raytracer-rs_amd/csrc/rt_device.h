@@ -349,7 +349,11 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
             for (int k = 0; k < count; k++) {
                 const uint32_t off = (uint32_t)(first + k) * 48u;
                 const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
-                if (COUNT) (*n_tris)++;
+                if (COUNT) {
+                    (*n_tris)++;
+                    // bit 31..16 of the counter: triangle-loop iterations the WAVE runs (counted by its first active lane)
+                    if (__ffsll(__ballot(1)) - 1 == (int)(threadIdx.x & 63u)) (*n_tris) += 0x10000u;
+                }
                 float t;
                 if (tri_hit(f3(u2f(a.x), u2f(a.y), u2f(a.z)), f3(u2f(b.x), u2f(b.y), u2f(b.z)), f3(u2f(c.x), u2f(c.y), u2f(c.z)), o, d, t_min, t_max, false, &t)) {
                     const int prim = (int)a.w;

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     hit[i] = make_float4(t_obj, __int_as_float(code), 0.0f, 0.0f);
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
-        atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+        atomicAdd(&ctl->h.tris, (unsigned long long)(nt & 0xFFFFu));
+        atomicAdd(&ctl->h.wave_tri_iters, (unsigned long long)(nt >> 16));
         atomicAdd(&ctl->h.hist_ray[min(15, 32 - __clz((int)nn))], 1ull);
         uint32_t wmax = nn;
         for (int sh = 32; sh > 0; sh >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, sh));
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
-        atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+        atomicAdd(&ctl->h.tris, (unsigned long long)(nt & 0xFFFFu));
     }
 }
 

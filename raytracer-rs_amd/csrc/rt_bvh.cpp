@@ -5,7 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <deque>
+#include <queue>
 #include <limits>
 
 namespace rtd {
@@ -198,20 +198,22 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
         return b.nodes[nd.left].box.area() >= b.nodes[nd.right].box.area();
     };
 
-    // numbering (the same for every order): breadth-first for the first max_top nodes, depth-first for the rest
+    // numbering (the same for every order): the first max_top nodes are the ones rays meet most often — starting at
+    // the root, always the not yet numbered child with the largest surface (a random ray crosses a box with probability
+    // proportional to its surface) — the rest follow depth-first.  The kernels keep the first group in LDS.
     std::vector<int> index(nn, -1);
     int next_index = 0;
     {
-        std::deque<int> q;
-        q.push_back(root);
+        auto cmp = [&](int x, int y) { return b.nodes[x].box.area() < b.nodes[y].box.area(); };
+        std::priority_queue<int, std::vector<int>, decltype(cmp)> q(cmp);
+        q.push(root);
         while (!q.empty() && next_index < max_top) {
-            int id = q.front();
-            q.pop_front();
+            int id = q.top();
+            q.pop();
             index[id] = next_index++;
             if (b.nodes[id].left >= 0) {
-                const bool lf = first_child_is_left(b.nodes[id], 8);
-                q.push_back(lf ? b.nodes[id].left : b.nodes[id].right);
-                q.push_back(lf ? b.nodes[id].right : b.nodes[id].left);
+                q.push(b.nodes[id].left);
+                q.push(b.nodes[id].right);
             }
         }
     }

@@ -22,7 +22,7 @@ struct BvhBuild {
     std::vector<float> tris;  // 12 floats per triangle in leaf order: v0.xyz, prim, e1.xyz, mat, e2.xyz, 0
     int n_nodes = 0;
     int n_orders = 1;         // 8: one node array per direction octant (bit a set = component a negative); 1: direction-independent order
-    int n_top = 0;            // nodes [0, n_top) are the breadth-first top of the tree
+    int n_top = 0;            // nodes [0, n_top) are the part of the tree rays meet most often (largest boxes, parents before children)
     int max_depth = 0;
 };
 

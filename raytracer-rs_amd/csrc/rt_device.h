@@ -113,7 +113,7 @@ struct DevLight {
 // BVH node, 32 B: a = (xmin, xmax, ymin, ymax), b = (zmin, zmax, link, miss).  link >= 0: index of the first child
 // (inner node); link < 0: leaf holding triangles [first, first+count) with ~link = first*8 + (count-1).  miss = node to
 // continue with when the box is missed or the subtree/leaf is done (-1 = traversal finished).  Nodes [0, n_top) are the
-// top of the tree in breadth-first order (the part each workgroup keeps in LDS); the rest follow in depth-first order.
+// part of the tree rays meet most often (largest boxes first, parents before children: the part each workgroup keeps in LDS); the rest follow in depth-first order.
 // `nodes` holds n_orders copies of the array (1, or 8 = one per sign octant of the ray direction) that differ only in
 // link and miss, i.e. in the order children are visited.
 // Triangle, 48 B: (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, unused) with e1 = v1-v0, e2 = v2-v0.

@@ -73,6 +73,36 @@ __device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)
     __syncthreads(); // sm may be reused by the next call
 }
 
+// Append with a target segment per element: two path nodes (next queue) and one shadow ray (shadow queue) per lane.
+// Elements are counted per segment in LDS (the returning LDS atomic is the element's rank inside the workgroup), then
+// one returning global atomic per non-empty (queue, segment) reserves the slots.  Every thread must call it.
+struct BlockAppendSeg {
+    uint32_t cnt[2][RT_NSEG];
+    uint32_t base[2][RT_NSEG];
+};
+static_assert(2 * RT_NSEG <= BLOCK, "one thread per (queue, segment) counter");
+
+__device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const uint32_t (&seg)[3], uint32_t (&slot)[3]) {
+    if (threadIdx.x < 2 * RT_NSEG) (&sm.cnt[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t rank[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) rank[k] = valid[k] ? atomicAdd(&sm.cnt[k == 2 ? 1 : 0][seg[k]], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < 2 * RT_NSEG) {
+        const uint32_t q = threadIdx.x / RT_NSEG, sg = threadIdx.x % RT_NSEG;
+        const uint32_t c = sm.cnt[q][sg];
+        sm.base[q][sg] = c ? atomicAdd(q ? &ctl->seg_shadow[sg].v : &ctl->seg_out[sg].v, c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) slot[k] = valid[k] ? sm.base[k == 2 ? 1 : 0][seg[k]] + rank[k] : 0u;
+    __syncthreads(); // sm may be reused by the next call
+}
+
+// segment of its class a workgroup appends to (any choice is correct; spreading by workgroup keeps the counters apart)
+__device__ __forceinline__ uint32_t ray_segment(bool heavy, uint32_t spread) { return (heavy ? RT_NSEG_HALF : 0u) + spread % RT_NSEG_HALF; }
+
 __device__ __forceinline__ void add_pixel(float *planes, uint32_t n_pixels, uint32_t pixel, F3 c) {
     atomicAdd(planes + pixel, c.x);
     atomicAdd(planes + n_pixels + pixel, c.y);
@@ -336,14 +366,14 @@ template <int SHADER>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
-    __shared__ BlockAppend sm;
+    __shared__ BlockAppendSeg sm;
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     if (bx * BLOCK >= n_seg) return;
     const uint32_t il = bx * BLOCK + threadIdx.x;
     const uint32_t i = seg * seg_capacity + il;
-    const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF, oseg_h = RT_NSEG_HALF + oseg_l;
+    const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
 
     bool have0 = false, have1 = false, have_s = false;
     Node c0, c1;
@@ -465,17 +495,16 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const bool heavy1 = have1 && ray_is_heavy(sc, c1.o, c1.d, rc.t_min, rc.t_max);
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
     const bool heavy_s = nee && ray_is_heavy(sc, s_o, s_d, rc.t_min, 1.0f - rc.t_min);
-    const bool flag[6] = {have0 && !heavy0, have1 && !heavy1, heavy0, heavy1, nee && !heavy_s, heavy_s};
-    uint32_t *const counter[4] = {&ctl->seg_out[oseg_l].v, &ctl->seg_out[oseg_h].v, &ctl->seg_shadow[oseg_l].v, &ctl->seg_shadow[oseg_h].v};
-    uint32_t slot[6];
-    block_append(sm, flag, counter, slot);
+    const bool valid3[3] = {have0, have1, nee};
+    const uint32_t seg3[3] = {have0 ? ray_segment(heavy0, bx + seg) : 0u, have1 ? ray_segment(heavy1, bx + seg) : 0u,
+                              nee ? ray_segment(heavy_s, bx + seg) : 0u};
+    uint32_t slot[3];
+    block_append_seg(sm, ctl, valid3, seg3, slot);
     if (have0) {
-        const uint32_t sl = heavy0 ? slot[2] : slot[0];
-        if (sl < seg_capacity) store_node(out, (heavy0 ? oseg_h : oseg_l) * seg_capacity + sl, c0); else ctl->h.overflow = 1;
+        if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0); else ctl->h.overflow = 1;
     }
     if (have1) {
-        const uint32_t sl = heavy1 ? slot[3] : slot[1];
-        if (sl < seg_capacity) store_node(out, (heavy1 ? oseg_h : oseg_l) * seg_capacity + sl, c1); else ctl->h.overflow = 1;
+        if (slot[1] < seg_capacity) store_node(out, seg3[1] * seg_capacity + slot[1], c1); else ctl->h.overflow = 1;
     }
     const uint32_t oseg = oseg_l; // the Whitted multi-ray path below does not classify
 
@@ -555,9 +584,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
         }
     } else {
         if (have_s) {
-            const uint32_t slot_s = heavy_s ? slot[5] : slot[4];
+            const uint32_t slot_s = slot[2];
             if (slot_s < shadow_seg_capacity) {
-                const uint32_t si = (heavy_s ? oseg_h : oseg_l) * shadow_seg_capacity + slot_s;
+                const uint32_t si = seg3[2] * shadow_seg_capacity + slot_s;
                 sh.a[si] = make_float4(s_o.x, s_o.y, s_o.z, s_d.x);
                 sh.b[si] = make_float4(s_d.y, s_d.z, s_c.x, s_c.y);
                 sh.c[si] = make_float2(s_c.z, __uint_as_float(s_pixel));

@@ -46,7 +46,7 @@ struct Builder {
     std::vector<TmpNode> nodes;
     int max_depth = 0;
 
-    int max_leaf = 1; // measured on MI355X: one triangle per leaf beats 2 and 4 (a wave runs the triangle test of every leaf any of its lanes enters)
+    int max_leaf = 2; // measured on MI355X: 1 or 2 triangles per leaf beat 4 (a wave runs the triangle tests of every leaf any of its lanes enters)
     static constexpr int BINS = 16;
 
     int build(int first, int count, int depth) {

@@ -307,7 +307,12 @@ __device__ __forceinline__ void fill_top_cache(const DevScene &sc, float4 *lds_n
 // One box test per visited node, 3 packed multiply-adds for the six plane distances: t = plane * (1/d) - o * (1/d).
 // A component of d that is zero (or so small that the products overflow) turns that axis' distances into NaN or
 // infinities; min/max drop NaN operands, so such an axis never culls.
-template <bool ANY_HIT, bool COUNT, bool USE_LDS = false>
+//
+// POSTPONE = false: a lane that reaches a leaf tests its triangles at once (the other lanes of the wave wait).
+// POSTPONE = true : a lane that reaches a leaf waits until no lane of the wave has an inner node left, then all lanes
+// holding a leaf run the triangle tests together.  Pays for rays that only meet the few big triangles around them (a
+// wave of those would otherwise run the test once per leaf ANY lane enters); loses for long walks and occlusion queries.
+template <bool ANY_HIT, bool COUNT, bool USE_LDS = false, bool POSTPONE = false>
 __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     TriHit best{t_max, -1, -1};
@@ -322,8 +327,9 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
     const uint32_t g_base = octant * (uint32_t)sc.n_nodes * 32u;
     const float2 *l_box_b = reinterpret_cast<const float2 *>(lds_nodes + sc.n_top);
     const float2 *l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
-    int node = 0;
-    while (node >= 0) {
+
+    // box test of `node`; returns the node to continue with and, through *leaf, the packed triangle range of a leaf that was hit (else -1)
+    auto step = [&](int node, int *leaf) -> int {
         u32x4 na, nb;
         if (USE_LDS && node < sc.n_top) {
             const float4 fa = lds_nodes[node];
@@ -342,30 +348,46 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
         const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), best.t));
         const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
         const int link = (int)nb.z, miss = (int)nb.w;
-        node = (inside && link >= 0) ? link : miss;
-        if (inside && link < 0) {
-            const int packed = ~link;
-            const int first = packed >> 3, count = (packed & 7) + 1;
-            for (int k = 0; k < count; k++) {
-                const uint32_t off = (uint32_t)(first + k) * 48u;
-                const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
-                if (COUNT) {
-                    (*n_tris)++;
-                    // bit 31..16 of the counter: triangle-loop iterations the WAVE runs (counted by its first active lane)
-                    if (__ffsll(__ballot(1)) - 1 == (int)(threadIdx.x & 63u)) (*n_tris) += 0x10000u;
-                }
-                float t;
-                if (tri_hit(f3(u2f(a.x), u2f(a.y), u2f(a.z)), f3(u2f(b.x), u2f(b.y), u2f(b.z)), f3(u2f(c.x), u2f(c.y), u2f(c.z)), o, d, t_min, t_max, false, &t)) {
-                    const int prim = (int)a.w;
-                    if (ANY_HIT) {
-                        best.t = t; best.tri = first + k; best.prim = prim;
-                        return best;
-                    }
-                    if (t < best.t || (t == best.t && prim > best.prim)) {
-                        best.t = t; best.tri = first + k; best.prim = prim;
-                    }
-                }
+        *leaf = (inside && link < 0) ? ~link : -1;
+        return (inside && link >= 0) ? link : miss;
+    };
+    // exact tests of a leaf's triangles; true = an occlusion query is decided
+    auto test_leaf = [&](int packed) -> bool {
+        const int first = packed >> 3, count = (packed & 7) + 1;
+        for (int k = 0; k < count; k++) {
+            const uint32_t off = (uint32_t)(first + k) * 48u;
+            const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
+            if (COUNT) {
+                (*n_tris)++;
+                // bit 31..16 of the counter: triangle-loop iterations the WAVE runs (counted by its first active lane)
+                if (__ffsll(__ballot(1)) - 1 == (int)(threadIdx.x & 63u)) (*n_tris) += 0x10000u;
             }
+            float t;
+            if (tri_hit(f3(u2f(a.x), u2f(a.y), u2f(a.z)), f3(u2f(b.x), u2f(b.y), u2f(b.z)), f3(u2f(c.x), u2f(c.y), u2f(c.z)), o, d, t_min, t_max, false, &t)) {
+                const int prim = (int)a.w;
+                // equal t: the later primitive of the world list wins (hitable.rs:44-50 + geometry.rs:53)
+                if (ANY_HIT || t < best.t || (t == best.t && prim > best.prim)) {
+                    best.t = t; best.tri = first + k; best.prim = prim;
+                }
+                if (ANY_HIT) return true;
+            }
+        }
+        return false;
+    };
+
+    int node = 0;
+    if (POSTPONE) {
+        for (;;) {
+            int leaf = -1;
+            while (node >= 0 && leaf < 0) node = step(node, &leaf);
+            if (leaf < 0) break;
+            if (test_leaf(leaf)) break;
+        }
+    } else {
+        while (node >= 0) {
+            int leaf;
+            node = step(node, &leaf);
+            if (leaf >= 0 && test_leaf(leaf)) break;
         }
     }
     return best;
@@ -373,10 +395,10 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
 
 // world.objects.hit (hitable.rs:35-62): triangles through the BVH, then spheres and cylinders in order.  A sphere or
 // cylinder needs t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.
-template <bool COUNT, bool USE_LDS = false>
+template <bool COUNT, bool USE_LDS = false, bool POSTPONE = false>
 __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max, float *t_out,
                                           int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
-    TriHit th = bvh_traverse<false, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    TriHit th = bvh_traverse<false, COUNT, USE_LDS, POSTPONE>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
     float closest = th.t;
     int code = th.tri >= 0 ? hit_code(HIT_KIND_TRI, th.tri) : HIT_NONE;
     int prim = th.prim;

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     float t_obj;
     int code, prim;
     uint32_t nn = 0, nt = 0;
-    world_hit<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
+    if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     hit[i] = make_float4(t_obj, __int_as_float(code), 0.0f, 0.0f);
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);

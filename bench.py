@@ -109,12 +109,13 @@ def main() -> int:
     # aggregate over ranks: slowest rank's time, everyone's rays
     rays_local = float(sum(s.rays_closest + s.rays_shadow for s in stats))
     cam_local = float(sum(s.camera_samples for s in stats))
-    agg = torch.tensor([rays_local, cam_local], dtype=torch.float64, device=dev)
+    closest_local = float(sum(s.rays_closest for s in stats))
+    agg = torch.tensor([rays_local, cam_local, closest_local], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays, total_cam = agg.tolist()
+    total_rays, total_cam, total_closest = agg.tolist()
     elapsed = float(tmax.item())
 
     result = None
@@ -178,6 +179,21 @@ def main() -> int:
             total_bytes = sum(units * bpu for units, bpu, _, _ in per_unit.values()) / steps
             roofline["whole_step"] = {"algorithmic_bytes": round(total_bytes), "achieved": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                       "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 4), "unit": "GB/s"}
+            # The per-ray figure that also counts geometry fetches (32 B ray + 16 B hit + 32 B per visited node + 36 B per
+            # triangle test + 16 / 24 B per sphere / cylinder, 64 B of path state per closest-hit ray, 12 B per camera sample)
+            # and the matching arithmetic (25 flop per node, 51 per triangle, 30 / 60 per sphere / cylinder, 150 per shaded
+            # hit): most of those bytes are served by LDS / L1 / L2, so their rate may exceed the HBM peak; the flop rate is
+            # priced against the non-fused FP32 vector rate (157.3 / 2 TFLOP/s: the kernels are built without contraction).
+            if nodes_per_ray > 0:
+                geo_b = 32 * nodes_per_ray + 36 * tris_per_ray + 16 * d.n_sph + 24 * d.n_cyl
+                geo_f = 25 * nodes_per_ray + 51 * tris_per_ray + 30 * d.n_sph + 60 * d.n_cyl
+                frame_b = total_rays * (48 + geo_b) + total_closest * 64 + total_cam * 12  # all ranks, all timed steps
+                frame_f = total_rays * geo_f + total_closest * 150
+                sec = ms_per_step * 1e-3 * steps
+                roofline["with_geometry_fetches"] = {
+                    "bytes_per_ray": round(48 + geo_b, 1), "flops_per_ray": round(geo_f, 1),
+                    "achieved_GBps": round(frame_b / sec / 1e9, 1), "achieved_TFLOPs": round(frame_f / sec / 1e12, 2),
+                    "valu_peak_TFLOPs": 78.65, "valu_frac": round(frame_f / sec / 1e12 / 78.65, 4)}
             roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)
             roofline["nodes_per_ray"] = round(nodes_per_ray, 2)
             roofline["tris_per_ray"] = round(tris_per_ray, 2)

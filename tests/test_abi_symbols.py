@@ -67,3 +67,23 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"oracle_py|liboracle|oracle/|orc_[a-z_]+\(", txt):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_rust_sys_declarations_follow_the_header(rt):
+    """bindings/rust (source only, never compiled here): same functions as rt_api.h, same field order as the ctypes mirrors."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "raytracer-mi355x-sys", "src", "lib.rs")).read()
+    fns = sorted(set(re.findall(r"pub fn (rt_[a-z0-9_]+)\s*\(", src)))
+    assert fns == declared_functions("rt_api.h")
+    rust_type = {C.c_int32: "i32", C.c_uint32: "u32", C.c_float: "f32", C.c_uint64: "u64", C.c_double: "f64"}
+    for name, cls in (("rt_material", rt.Material), ("rt_light", rt.Light), ("rt_object", rt.Object), ("rt_scene_desc", rt.SceneDesc),
+                      ("rt_camera", rt.Camera), ("rt_params", rt.Params), ("rt_stats", rt.Stats)):
+        body = re.search(r"pub struct %s\s*\{(.*?)\}" % name, src, flags=re.S).group(1)
+        fields = re.findall(r"pub ([a-z0-9_]+)\s*:\s*([^,]+?)\s*(?:,|$)", body.replace("\n", " "))
+        assert [f for f, _ in fields] == [f[0] for f in cls._fields_], name
+        for (fname, rtype), (_, ctype) in zip(fields, cls._fields_):
+            if ctype in rust_type:
+                assert rtype == rust_type[ctype], (name, fname)
+            elif hasattr(ctype, "_length_"):
+                assert rtype == "[%s; %d]" % (rust_type[ctype._type_], ctype._length_), (name, fname)
+            else:
+                assert rtype.startswith("*const"), (name, fname)

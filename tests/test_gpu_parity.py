@@ -151,6 +151,30 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
     ds.close()
 
 
+KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"},
+         {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"}]
+
+
+@pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_scheduling_knobs_do_not_change_results(rt, orc, gpu_ctx, monkeypatch, env):
+    """Tree shape, visiting order, LDS share, ray binning and stream overlap are free choices: same hits, same image."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H, spp = 80, 45, 3
+    hs = rt.HostScene("utah", W / H)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)  # the BVH knobs are read here, the others by the render call
+    osc = orc.OracleScene(hs.desc, 1)
+    p = rt.default_params(W, H, spp)
+    gp, gt = ds.primary_hits(hs.camera, p)
+    cp, ct = osc.primary_hits(hs.camera, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    ga, gs = ds.render(hs.camera, p)
+    ca, cs = osc.render(hs.camera, p)
+    assert_radiance_close(ga, ca)
+    assert gs.camera_samples == W * H * spp
+    ds.close()
+
+
 def test_light_spectrum_is_linear(rt, gpu_ctx):
     hs = rt.HostScene("head", 1.0)
     d = hs.desc

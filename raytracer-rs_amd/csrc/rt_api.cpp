@@ -516,19 +516,35 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
 
-    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`
-    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 23);
+    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`.  The default keeps 32 Mi rays in
+    // flight (measured: 8 Mi -> 32 Mi is 3-8 % faster, the few long walks of a launch overlap with more short ones);
+    // that is about 50 GB of queues, so without an explicit RT_QUEUE_TARGET the level is halved until the queues fit
+    // into half of the free device memory.
+    const char *target_env = std::getenv("RT_QUEUE_TARGET");
+    const bool target_given = target_env && *target_env;
+    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 25);
     // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
     // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
     uint32_t per_node = 1;
     if (p->shader == RT_SHADER_WHITTED) per_node = (uint32_t)std::max(1, s->n_point_lights + s->n_disk_lights * std::max(1, p->light_samples));
     if (per_node > 1) target = std::max<uint32_t>(1u << 16, target / 8);
     if (total < target) target = (uint32_t)total;
-    target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
-    // a segment holds 8x its even share of the refill level: bursts of branching (Microfacet spawns two rays per hit)
-    // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
-    const uint32_t seg_capacity = 8u * (target / RT_NSEG);
-    const uint32_t shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
+    uint32_t seg_capacity = 0, shadow_seg_capacity = 0;
+    for (;;) {
+        target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
+        // a segment holds 8x its even share of the refill level: bursts of branching (Microfacet spawns two rays per hit)
+        // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
+        seg_capacity = 8u * (target / RT_NSEG);
+        shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
+        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 16) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
+        const bool grows = (size_t)seg_capacity * RT_NSEG > ctx->capacity || (size_t)shadow_seg_capacity * RT_NSEG > ctx->shadow_capacity;
+        if (target_given || !grows || target <= (1u << 20)) break;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+        const size_t held = ctx->capacity * (size_t)(2 * 48 + 16) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
+        if (need <= (free_b + held) / 2) break;
+        target /= 2;
+    }
     const size_t plane_stride = rcst.plane_stride; // the kernels index the colour planes by tile
     rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, plane_stride);
     if (rc) return rc;

@@ -43,7 +43,16 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count-pass", action="store_true", help="skip the untimed BVH work-counting pass (for PMC profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path")
     args = ap.parse_args()
+
+    # The renderer overlaps two streams, torch and RCCL bring theirs; HIP's default of 4 hardware queues per process
+    # makes streams share queues (and lose the overlap) once RCCL is up.  Must be set before the HIP runtime starts.
+    try:
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    except ValueError:
+        pass
 
     import numpy as np
     import torch
@@ -54,11 +63,20 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL creates its streams at the first collective.  Do that before the renderer creates its two streams: a
+        # process has few hardware queues (GPU_MAX_HW_QUEUES), and streams that share one do not overlap.
+        warm = torch.zeros(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -92,7 +110,7 @@ def main() -> int:
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -112,7 +130,7 @@ def main() -> int:
     closest_local = float(sum(s.rays_closest for s in stats))
     agg = torch.tensor([rays_local, cam_local, closest_local], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays, total_cam, total_closest = agg.tolist()
@@ -245,7 +263,7 @@ def main() -> int:
         }
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0

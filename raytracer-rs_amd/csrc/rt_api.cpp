@@ -237,7 +237,7 @@ int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, in
     std::vector<int32_t> prim((size_t)n_tri), mat((size_t)n_tri, 0);
     for (int i = 0; i < n_tri; i++) prim[(size_t)i] = i;
     BvhBuild b;
-    build_bvh(tri_v, prim.data(), mat.data(), n_tri, max_top, ordered != 0, (int)env_u32("RT_BVH_LEAF", 2), &b);
+    build_bvh(tri_v, prim.data(), mat.data(), n_tri, max_top, ordered != 0, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &b);
     if (n_nodes) *n_nodes = b.n_nodes;
     if (n_top) *n_top = b.n_top;
     if (n_orders) *n_orders = b.n_orders;
@@ -412,7 +412,7 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     BvhBuild bvh;
     const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 32);
     const bool ordered = env_u32_allow_zero("RT_BVH_ORDERED", 1) != 0;
-    build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), &bvh);
+    build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh);
     UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
     UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
     UP(s->sph, d->sph, d->n_sph, float4);

@@ -154,7 +154,8 @@ inline float int_bits(int v) {
 
 } // namespace
 
-void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, BvhBuild *out) {
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, int max_arity,
+               BvhBuild *out) {
     out->nodes.clear();
     out->tris.clear();
     out->n_nodes = out->n_top = out->max_depth = 0;
@@ -188,20 +189,58 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
     }
     b.nodes.reserve(2 * (size_t)n_tri);
     int root = b.build(0, n_tri, 0);
-    const int nn = (int)b.nodes.size();
 
-    // Which child a ray of direction-sign class `order` looks at first.  Classes 0..7 are the sign octants (bit a set:
-    // the direction's component a is negative): the child on the side the ray comes from goes first, so that a hit
-    // found there culls the other child.  Class 8 ignores the direction: the child with the larger surface first.
-    auto first_child_is_left = [&](const TmpNode &nd, int order) {
-        if (order < 8 && nd.axis >= 0) return ((order >> nd.axis) & 1) == 0;
-        return b.nodes[nd.left].box.area() >= b.nodes[nd.right].box.area();
+    // Widening.  An inner node X under P only pays for its box test if that test often fails: with k children the walk
+    // does 1 + p*k tests through X (p = chance that a ray meeting P also meets X, about area(X) / area(P)) against k
+    // without it, so X is dissolved into P's child list when p > (k-1)/k.  The threaded layout does not care how many
+    // children a node has.  Rays that start inside a room meet every box that spans the room: those nodes all go.
+    std::vector<std::vector<int>> kids(b.nodes.size());
+    for (size_t i = 0; i < b.nodes.size(); i++)
+        if (b.nodes[i].left >= 0) kids[i] = {b.nodes[i].left, b.nodes[i].right};
+    if (max_arity > 2) {
+        std::vector<int> todo{root};
+        while (!todo.empty()) {
+            const int pnode = todo.back();
+            todo.pop_back();
+            std::vector<int> &list = kids[pnode];
+            const float pa = b.nodes[pnode].box.area();
+            for (size_t i = 0; i < list.size();) {
+                const int x = list[i];
+                const size_t k = kids[x].size();
+                if (k >= 2 && list.size() + k - 1 <= (size_t)max_arity && b.nodes[x].box.area() * (float)k > pa * (float)(k - 1)) {
+                    const std::vector<int> grand = kids[x]; // x's children take x's place and are looked at in turn
+                    kids[x].clear();
+                    list.erase(list.begin() + (long)i);
+                    list.insert(list.begin() + (long)i, grand.begin(), grand.end());
+                } else {
+                    i++;
+                }
+            }
+            for (int c : list)
+                if (!kids[c].empty()) todo.push_back(c);
+        }
+    }
+
+    // Visiting order of a node's children for a ray of direction-sign class `order`.  Classes 0..7 are the sign octants
+    // (bit a set: the direction's component a is negative): children sorted along the octant's diagonal, the side the
+    // ray comes from first, so that a hit found there culls the rest.  Class 8 ignores the direction: larger surface first.
+    auto sorted_kids = [&](int id, int order) {
+        std::vector<int> v = kids[id];
+        auto key = [&](int c) {
+            const Box &bx = b.nodes[c].box;
+            if (order >= 8) return -bx.area();
+            float kx = 0.0f;
+            for (int a = 0; a < 3; a++) kx += ((order >> a) & 1 ? -1.0f : 1.0f) * (bx.mn[a] + bx.mx[a]);
+            return kx;
+        };
+        std::stable_sort(v.begin(), v.end(), [&](int x, int y) { return key(x) < key(y); });
+        return v;
     };
 
     // numbering (the same for every order): the first max_top nodes are the ones rays meet most often — starting at
     // the root, always the not yet numbered child with the largest surface (a random ray crosses a box with probability
     // proportional to its surface) — the rest follow depth-first.  The kernels keep the first group in LDS.
-    std::vector<int> index(nn, -1);
+    std::vector<int> index(b.nodes.size(), -1);
     int next_index = 0;
     {
         auto cmp = [&](int x, int y) { return b.nodes[x].box.area() < b.nodes[y].box.area(); };
@@ -211,10 +250,7 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             int id = q.top();
             q.pop();
             index[id] = next_index++;
-            if (b.nodes[id].left >= 0) {
-                q.push(b.nodes[id].left);
-                q.push(b.nodes[id].right);
-            }
+            for (int c : kids[id]) q.push(c);
         }
     }
     out->n_top = next_index;
@@ -225,13 +261,11 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             int id = stack.back();
             stack.pop_back();
             if (index[id] < 0) index[id] = next_index++;
-            if (b.nodes[id].left >= 0) {
-                const bool lf = first_child_is_left(b.nodes[id], 8);
-                stack.push_back(lf ? b.nodes[id].right : b.nodes[id].left);
-                stack.push_back(lf ? b.nodes[id].left : b.nodes[id].right);
-            }
+            const std::vector<int> v = sorted_kids(id, 8);
+            for (size_t i = v.size(); i-- > 0;) stack.push_back(v[i]);
         }
     }
+    const int nn = next_index; // dissolved nodes are gone
 
     // threading, once per order: miss(node) = first node of whatever follows the node's subtree in visiting order
     out->n_orders = ordered ? 8 : 1;
@@ -251,12 +285,10 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             dst[2] = nd.box.mn[1]; dst[3] = nd.box.mx[1];
             dst[4] = nd.box.mn[2]; dst[5] = nd.box.mx[2];
             dst[7] = int_bits(it.next);
-            if (nd.left >= 0) {
-                const bool lf = first_child_is_left(nd, order);
-                const int c0 = lf ? nd.left : nd.right, c1 = lf ? nd.right : nd.left;
-                dst[6] = int_bits(index[c0]);
-                stack.push_back({c0, index[c1]});
-                stack.push_back({c1, it.next});
+            if (!kids[it.id].empty()) {
+                const std::vector<int> v = sorted_kids(it.id, order);
+                dst[6] = int_bits(index[v[0]]);
+                for (size_t i = 0; i < v.size(); i++) stack.push_back({v[i], i + 1 < v.size() ? index[v[i + 1]] : it.next});
             } else {
                 dst[6] = int_bits(~(nd.first * 8 + (nd.count - 1)));
             }

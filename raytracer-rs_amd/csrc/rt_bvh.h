@@ -26,7 +26,9 @@ struct BvhBuild {
     int max_depth = 0;
 };
 
-// tri_v: 9 floats per triangle; prim_id / mat per triangle.  max_top bounds n_top, max_leaf (1..4) the triangles per leaf.
-void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, BvhBuild *out);
+// tri_v: 9 floats per triangle; prim_id / mat per triangle.  max_top bounds n_top, max_leaf (1..4) the triangles per leaf,
+// max_arity the children per node after widening (2 = keep the binary tree).
+void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, int max_arity,
+               BvhBuild *out);
 
 } // namespace rtd

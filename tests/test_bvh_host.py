@@ -126,9 +126,13 @@ def test_structure(rt, n, ordered):
         for node in range(nodes.shape[1]):
             lk = int(link[node])
             if lk >= 0:
-                sib = int(miss[lk])  # the second child is where the first child's subtree exits to
-                for c in (lk, sib):
+                # children: the first one, then wherever a child's subtree exits to, until the exit is the parent's own
+                c, n_children = lk, 0
+                while c != int(miss[node]):
                     assert (nodes[k, c, [0, 2, 4]] >= nodes[k, node, [0, 2, 4]]).all() and (nodes[k, c, [1, 3, 5]] <= nodes[k, node, [1, 3, 5]]).all()
+                    n_children += 1
+                    c = int(miss[c])
+                assert 2 <= n_children <= 8
 
 
 @pytest.mark.parametrize("flat", [False, True])
@@ -155,6 +159,31 @@ def test_walk_matches_scan_in_every_order(rt, flat):
         fewer += visited[octant] <= visited[octant ^ 7]
     assert hits >= 10
     assert fewer > 40  # front-to-back order visits no more nodes than back-to-front for most rays
+
+
+def test_widening_dissolves_nodes_that_cannot_cull(rt, monkeypatch):
+    """A closed room of 6 quads: every inner box spans the room, so a widened tree has fewer nodes than the binary one."""
+    q = []
+    for axis in range(3):
+        for side in (-1.0, 1.0):
+            u, v = [a for a in range(3) if a != axis]
+            c = np.zeros((4, 3))
+            c[:, axis] = side
+            c[:, u] = [-1, 1, 1, -1]
+            c[:, v] = [-1, -1, 1, 1]
+            q += [np.concatenate([c[0], c[1], c[2]]), np.concatenate([c[0], c[2], c[3]])]
+    tri_v = np.array(q, F)
+    monkeypatch.setenv("RT_BVH_ARITY", "2")
+    binary, _, _ = rt.bvh_build_host(tri_v, 8, True)
+    monkeypatch.setenv("RT_BVH_ARITY", "8")
+    wide, tris, _ = rt.bvh_build_host(tri_v, 8, True)
+    assert wide.shape[1] < binary.shape[1]
+    o, d = np.array([0.1, -0.2, 0.3], F), np.array([0.3, 1.0, -0.2], F)
+    want = brute(tris, o, d, F(1e-3), F(1e7))
+    assert want[1] >= 0
+    for k in range(8):
+        t, p, visited = walk(wide[k], tris, o, d, F(1e-3), F(1e7))
+        assert (t, p) == want and visited <= wide.shape[1]
 
 
 def test_empty_and_argument_errors(rt):

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 #include <limits>
@@ -194,6 +195,7 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
     // does 1 + p*k tests through X (p = chance that a ray meeting P also meets X, about area(X) / area(P)) against k
     // without it, so X is dissolved into P's child list when p > (k-1)/k.  The threaded layout does not care how many
     // children a node has.  Rays that start inside a room meet every box that spans the room: those nodes all go.
+    // (Measured: thresholds 0.7x to 2.5x this one are all slower, on a wall-dominated and on a mesh-dominated scene.)
     std::vector<std::vector<int>> kids(b.nodes.size());
     for (size_t i = 0; i < b.nodes.size(); i++)
         if (b.nodes[i].left >= 0) kids[i] = {b.nodes[i].left, b.nodes[i].right};

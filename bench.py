@@ -166,8 +166,8 @@ def main() -> int:
         d = hs.desc
         cache_bytes_per_ray = 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
         per_unit = {  # kernel: (units over the timed steps, algorithmic HBM bytes per unit, launches, total ms)
-            "k_extend": (closest, 32 + 16, sum(s.launches_extend for s in stats), sum(s.ms_extend for s in stats)),
-            "k_shade": (closest, 48 + 16 + 48 * children_per_node + 40 * shadow_per_node, sum(s.launches_shade for s in stats), sum(s.ms_shade for s in stats)),
+            "k_extend": (closest, 32 + 8, sum(s.launches_extend for s in stats), sum(s.ms_extend for s in stats)),
+            "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node, sum(s.launches_shade for s in stats), sum(s.ms_shade for s in stats)),
             "k_shadow": (shadow, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
         }
         traffic_file = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
@@ -197,7 +197,7 @@ def main() -> int:
             total_bytes = sum(units * bpu for units, bpu, _, _ in per_unit.values()) / steps
             roofline["whole_step"] = {"algorithmic_bytes": round(total_bytes), "achieved": round(total_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                       "frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0, 4), "unit": "GB/s"}
-            # The per-ray figure that also counts geometry fetches (32 B ray + 16 B hit + 32 B per visited node + 36 B per
+            # The per-ray figure that also counts geometry fetches (32 B ray + 8 B hit + 32 B per visited node + 36 B per
             # triangle test + 16 / 24 B per sphere / cylinder, 64 B of path state per closest-hit ray, 12 B per camera sample)
             # and the matching arithmetic (25 flop per node, 51 per triangle, 30 / 60 per sphere / cylinder, 150 per shaded
             # hit): most of those bytes are served by LDS / L1 / L2, so their rate may exceed the HBM peak; the flop rate is
@@ -205,11 +205,11 @@ def main() -> int:
             if nodes_per_ray > 0:
                 geo_b = 32 * nodes_per_ray + 36 * tris_per_ray + 16 * d.n_sph + 24 * d.n_cyl
                 geo_f = 25 * nodes_per_ray + 51 * tris_per_ray + 30 * d.n_sph + 60 * d.n_cyl
-                frame_b = total_rays * (48 + geo_b) + total_closest * 64 + total_cam * 12  # all ranks, all timed steps
+                frame_b = total_rays * (40 + geo_b) + total_closest * 64 + total_cam * 12  # all ranks, all timed steps
                 frame_f = total_rays * geo_f + total_closest * 150
                 sec = ms_per_step * 1e-3 * steps
                 roofline["with_geometry_fetches"] = {
-                    "bytes_per_ray": round(48 + geo_b, 1), "flops_per_ray": round(geo_f, 1),
+                    "bytes_per_ray": round(40 + geo_b, 1), "flops_per_ray": round(geo_f, 1),
                     "achieved_GBps": round(frame_b / sec / 1e9, 1), "achieved_TFLOPs": round(frame_f / sec / 1e12, 2),
                     "valu_peak_TFLOPs": 78.65, "valu_frac": round(frame_f / sec / 1e12 / 78.65, 4)}
             roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)

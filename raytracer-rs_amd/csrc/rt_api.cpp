@@ -77,8 +77,8 @@ struct rt_context {
     hipEvent_t shadow_done = nullptr;
     // queue pool, sized on demand
     uint32_t capacity = 0, shadow_capacity = 0;
-    DevBuf<float4> qa[2], qb[2], qc[2], hit, sa[2], sb[2];
-    DevBuf<float2> sc2[2];
+    DevBuf<float4> qa[2], qb[2], qc[2], sa[2], sb[2];
+    DevBuf<float2> hit, sc2[2];
     DevBuf<float> planes, accum_tmp;
     DevBuf<int32_t> blocks, prim_tmp;
     DevBuf<float> t_tmp;
@@ -536,12 +536,12 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
         seg_capacity = 8u * (target / RT_NSEG);
         shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
-        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 16) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
+        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 8) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
         const bool grows = (size_t)seg_capacity * RT_NSEG > ctx->capacity || (size_t)shadow_seg_capacity * RT_NSEG > ctx->shadow_capacity;
         if (target_given || !grows || target <= (1u << 20)) break;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
-        const size_t held = ctx->capacity * (size_t)(2 * 48 + 16) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
+        const size_t held = ctx->capacity * (size_t)(2 * 48 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
         if (need <= (free_b + held) / 2) break;
         target /= 2;
     }

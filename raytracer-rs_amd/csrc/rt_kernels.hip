@@ -243,9 +243,9 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, C
 
 // ---- k_extend -------------------------------------------------------------------------------------------------------
 // grid (blocks, RT_NSEG): workgroup (bx, s) handles nodes [bx*256, bx*256+256) of segment s.
-// hit record: (t_obj, object code, -, -)
+// hit record: (t_obj, object code)
 template <bool COUNT, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t seg_capacity,
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float2 *hit, uint32_t seg_capacity,
                                                   uint32_t heavy_blocks) {
     extern __shared__ float4 lds_nodes[];
     uint32_t seg, bx;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
     if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
-    hit[i] = make_float4(t_obj, __int_as_float(code), 0.0f, 0.0f);
+    hit[i] = make_float2(t_obj, __int_as_float(code));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
         atomicAdd(&ctl->h.tris, (unsigned long long)(nt & 0xFFFFu));
@@ -365,7 +365,7 @@ __device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst
 // grid (blocks, RT_NSEG) like k_extend.  Children go to segment (bx + s) % RT_NSEG of the next queue, which spreads
 // every segment's offspring over all segments and keeps them level.
 template <int SHADER>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     __shared__ BlockAppendSeg sm;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
 
     if (il < n_seg) {
         Node nd = load_node(in, i);
-        const float4 h = hit[i];
+        const float2 h = hit[i];
         const float t_obj = h.x;
         const int code = __float_as_int(h.y);
         // world.lights.hit(r) (shader.rs:99): tested here, where every lane of the wave is busy, not in the traversal kernel
@@ -711,7 +711,7 @@ static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads
     return RT_NSEG_HALF * (*heavy_blocks + nblocks(light_threads));
 }
 
-void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float4 *hit, uint32_t light_threads,
+void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float2 *hit, uint32_t light_threads,
                    uint32_t heavy_threads, bool count) {
     uint32_t hb;
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
@@ -722,7 +722,7 @@ void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
 }
 
-void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float4 *hit,
+void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                   ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads) {
     uint32_t hb;
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);

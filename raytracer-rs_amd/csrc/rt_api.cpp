@@ -569,6 +569,11 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         std::memset(ctx->ctl_host, 0, sizeof(CtlHead));
         ctx->ctl_host->total = total;
         ctx->ctl_host->per_sample = n_blocks * 64u;
+        ctx->ctl_host->n_samples = (uint32_t)n_samples;
+        // samples of one 8x8 block generated together; bounded so that a chunk's candidate count stays below 2^30
+        uint32_t chunk_samples = env_u32("RT_TILE_SAMPLES", 16);
+        while (chunk_samples > 1 && (unsigned long long)n_blocks * 64ull * chunk_samples >= (1ull << 30)) chunk_samples /= 2;
+        ctx->ctl_host->chunk_samples = chunk_samples;
         HIP_TRY(hipMemcpyAsync(&ctx->ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int cur = 0, scur = 0;

@@ -42,9 +42,14 @@ struct CtlHead {
     uint32_t n_new;     // camera candidates to generate this iteration
     uint32_t max_in_light, max_in_heavy; // largest per-segment node count of each class before ray generation
     uint32_t max_sh_light, max_sh_heavy; // largest per-segment shadow-ray count queued by the previous iteration
-    uint32_t first_sample;    // sample index (relative to spp_begin) of the first camera candidate of this iteration
-    uint32_t first_rem;       // ... and its position inside that sample
+    // Camera candidates are numbered tile-major in chunks of `chunk_samples` samples: chunk -> 8x8 pixel block -> sample
+    // inside the chunk -> pixel inside the block.  The rays of one block are generated together and stay together in
+    // the queues, so the atomic adds of a wave fall into few cache lines.
+    uint32_t first_sample;    // first sample (relative to spp_begin) of the chunk the first candidate of this iteration lies in
+    uint32_t first_rem;       // ... and the candidate's position inside that chunk
     uint32_t per_sample;      // camera candidates per sample = 64 * number of 8x8 pixel blocks
+    uint32_t n_samples;       // samples of this render call (spp_end - spp_begin)
+    uint32_t chunk_samples;   // samples per chunk (the last chunk may hold fewer)
     uint32_t iterations;
     uint32_t done;      // nothing left to do
     uint32_t overflow;  // a queue segment ran out of room (the render call fails)

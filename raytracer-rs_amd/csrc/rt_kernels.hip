@@ -73,30 +73,52 @@ __device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)
     __syncthreads(); // sm may be reused by the next call
 }
 
-// Append with a target segment per element: two path nodes (next queue) and one shadow ray (shadow queue) per lane.
-// Elements are counted per segment in LDS (the returning LDS atomic is the element's rank inside the workgroup), then
-// one returning global atomic per non-empty (queue, segment) reserves the slots.  Every thread must call it.
+// Append of two path nodes (next queue) and one shadow ray (shadow queue) per lane, each light or heavy: four groups
+// (light nodes, heavy nodes, light shadow rays, heavy shadow rays), one counter each in segment `seg_l` of its class.
+// Inside a wave the elements keep lane order (ballot + mbcnt) and a wave's elements are contiguous: a wave of camera rays
+// is one 8x8 pixel tile, and rays that stay together keep their stores, their later loads and the atomic adds of their
+// shadow rays in few cache lines.  The waves of the workgroup are ordered by an LDS counter, and one returning global
+// atomic per non-empty group reserves the workgroup's slots.  Every thread must call it.
 struct BlockAppendSeg {
-    uint32_t cnt[2][RT_NSEG];
-    uint32_t base[2][RT_NSEG];
+    uint32_t cnt[4];
+    uint32_t base[4];
 };
-static_assert(2 * RT_NSEG <= BLOCK, "one thread per (queue, segment) counter");
 
-__device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const uint32_t (&seg)[3], uint32_t (&slot)[3]) {
-    if (threadIdx.x < 2 * RT_NSEG) (&sm.cnt[0][0])[threadIdx.x] = 0u;
-    __syncthreads();
-    uint32_t rank[3];
+__device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const bool (&heavy)[3], uint32_t seg_l,
+                                                 uint32_t (&slot)[3]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < 4u) sm.cnt[threadIdx.x] = 0u;
+    unsigned long long m[3][2];
 #pragma unroll
-    for (int k = 0; k < 3; k++) rank[k] = valid[k] ? atomicAdd(&sm.cnt[k == 2 ? 1 : 0][seg[k]], 1u) : 0u;
+    for (int k = 0; k < 3; k++) {
+        m[k][0] = __ballot(valid[k] && !heavy[k]);
+        m[k][1] = __ballot(valid[k] && heavy[k]);
+    }
+    const uint32_t n00 = (uint32_t)__popcll(m[0][0]), n01 = (uint32_t)__popcll(m[0][1]);
+    const uint32_t cnt0 = n00 + (uint32_t)__popcll(m[1][0]), cnt1 = n01 + (uint32_t)__popcll(m[1][1]);
+    const uint32_t cnt2 = (uint32_t)__popcll(m[2][0]), cnt3 = (uint32_t)__popcll(m[2][1]);
     __syncthreads();
-    if (threadIdx.x < 2 * RT_NSEG) {
-        const uint32_t q = threadIdx.x / RT_NSEG, sg = threadIdx.x % RT_NSEG;
-        const uint32_t c = sm.cnt[q][sg];
-        sm.base[q][sg] = c ? atomicAdd(q ? &ctl->seg_shadow[sg].v : &ctl->seg_out[sg].v, c) : 0u;
+    uint32_t wave_base = 0;
+    if (lane < 4u) {
+        const uint32_t c = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : cnt3;
+        if (c) wave_base = atomicAdd(&sm.cnt[lane], c);
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 3; k++) slot[k] = valid[k] ? sm.base[k == 2 ? 1 : 0][seg[k]] + rank[k] : 0u;
+    if (threadIdx.x < 4u) {
+        const uint32_t c = sm.cnt[threadIdx.x];
+        uint32_t *counter = threadIdx.x == 0u ? &ctl->seg_out[seg_l].v : threadIdx.x == 1u ? &ctl->seg_out[RT_NSEG_HALF + seg_l].v
+                          : threadIdx.x == 2u ? &ctl->seg_shadow[seg_l].v : &ctl->seg_shadow[RT_NSEG_HALF + seg_l].v;
+        sm.base[threadIdx.x] = c ? atomicAdd(counter, c) : 0u;
+    }
+    __syncthreads();
+    const uint32_t b0 = sm.base[0] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 0);
+    const uint32_t b1 = sm.base[1] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 1);
+    const uint32_t b2 = sm.base[2] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 2);
+    const uint32_t b3 = sm.base[3] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 3);
+    auto below = [&](unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+    slot[0] = heavy[0] ? b1 + below(m[0][1]) : b0 + below(m[0][0]);
+    slot[1] = heavy[1] ? b1 + n01 + below(m[1][1]) : b0 + n00 + below(m[1][0]);
+    slot[2] = heavy[2] ? b3 + below(m[2][1]) : b2 + below(m[2][0]);
     __syncthreads(); // sm may be reused by the next call
 }
 
@@ -179,10 +201,12 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     uint32_t n_new = 0;
     if (alive < target && remaining > 0) {
         unsigned long long room = target - alive;
+        if (room >= BLOCK) room &= ~(unsigned long long)(BLOCK - 1); // whole workgroups: a wave stays one block of one sample
         n_new = (uint32_t)(remaining < room ? remaining : room);
     }
-    h.first_sample = (uint32_t)(h.cursor / h.per_sample);
-    h.first_rem = (uint32_t)(h.cursor % h.per_sample);
+    const unsigned long long chunk_candidates = (unsigned long long)h.per_sample * h.chunk_samples;
+    h.first_sample = (uint32_t)(h.cursor / chunk_candidates) * h.chunk_samples;
+    h.first_rem = (uint32_t)(h.cursor % chunk_candidates);
     h.cursor += n_new;
     h.n_new = n_new;
     h.n_alive = alive;
@@ -195,8 +219,8 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
 }
 
 // ---- k_raygen -------------------------------------------------------------------------------------------------------
-// Camera candidates are numbered sample-major: candidate c -> sample c / per_sample, 8x8 pixel block
-// (c % per_sample) / 64, pixel c % 64 inside the block.  One wave = one 8x8 block of one sample.
+// Camera candidates are numbered chunk -> 8x8 pixel block -> sample inside the chunk -> pixel inside the block (see
+// CtlHead).  One wave = one 8x8 block of one sample, one workgroup = four samples of the same block.
 __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                                                   uint32_t seg_capacity) {
     __shared__ BlockAppend sm;
@@ -206,16 +230,24 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, C
     bool valid = false;
     Node n;
     if (g < n_new) {
-        const uint32_t per_sample = ctl->h.per_sample;
-        uint32_t r = ctl->h.first_rem + g; // < 2^25 + 2^24
-        uint32_t s_rel = ctl->h.first_sample + r / per_sample;
-        r = r % per_sample;
-        uint32_t bi = r >> 6, lane = r & 63u;
+        const uint32_t per_sample = ctl->h.per_sample, n_samples = ctl->h.n_samples, chunk_samples = ctl->h.chunk_samples;
+        uint32_t r = ctl->h.first_rem + g; // < 2^31: the host bounds per_sample * chunk_samples and the refill level
+        uint32_t s0 = ctl->h.first_sample;
+        uint32_t in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
+        while (in_chunk != 0u && r >= per_sample * in_chunk) { // the batch runs over into the next chunk(s)
+            r -= per_sample * in_chunk;
+            s0 += in_chunk;
+            in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
+        }
+        const uint32_t div = 64u * max(in_chunk, 1u);
+        const uint32_t bi = min(r / div, per_sample / 64u - 1u); // in range even if the counters were inconsistent
+        const uint32_t within = r - bi * div;
+        const uint32_t s_rel = s0 + (within >> 6), lane = within & 63u;
         uint32_t blk = blocks ? (uint32_t)blocks[bi] : bi;
         int x = (int)((blk % blocks_w) * 8u + (lane & 7u));
         int y = (int)((blk / blocks_w) * 8u + (lane >> 3));
         int k = rc.spp_begin + (int)s_rel;
-        if (x < rc.width && y < rc.height && pixel_selected(rc, x, y)) {
+        if (in_chunk != 0u && within < div && x < rc.width && y < rc.height && pixel_selected(rc, x, y)) {
             uint32_t pixel = (uint32_t)(y * rc.width + x);
             uint32_t pk = pixel_key(rc.seed, pixel);
             uint32_t nk = root_node_key((uint32_t)k);
@@ -498,10 +530,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
     const bool heavy_s = nee && ray_is_heavy(sc, s_o, s_d, rc.t_min, 1.0f - rc.t_min);
     const bool valid3[3] = {have0, have1, nee};
-    const uint32_t seg3[3] = {have0 ? ray_segment(heavy0, bx + seg) : 0u, have1 ? ray_segment(heavy1, bx + seg) : 0u,
-                              nee ? ray_segment(heavy_s, bx + seg) : 0u};
+    const bool heavy3[3] = {heavy0, heavy1, heavy_s};
+    const uint32_t seg3[3] = {ray_segment(heavy0, oseg_l), ray_segment(heavy1, oseg_l), ray_segment(heavy_s, oseg_l)};
     uint32_t slot[3];
-    block_append_seg(sm, ctl, valid3, seg3, slot);
+    block_append_seg(sm, ctl, valid3, heavy3, oseg_l, slot);
     if (have0) {
         if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0); else ctl->h.overflow = 1;
     }

@@ -143,7 +143,7 @@ def main() -> int:
         mrays = total_rays / elapsed / 1e6
 
         # ---- roofline of the dominant kernel, from this rank's timed steps (HIP events on the render stream)
-        # Algorithmic HBM bytes per unit (DESIGN.md "Kernels"): what one launch must stream to and from HBM.  BVH nodes and
+        # Algorithmic HBM bytes per unit: what one launch must stream to and from HBM.  BVH nodes and
         # triangles are NOT in these figures: the whole scene (a few MB) stays in L2 / Infinity Cache / LDS after the first
         # touch; their per-ray volume is reported beside it as cache_bytes_per_ray.
         closest = sum(s.rays_closest for s in stats)

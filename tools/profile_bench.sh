@@ -1,5 +1,5 @@
 #!/bin/bash
-# profile_round.sh TAG: full bench line, rocprofv3 kernel-trace stats and the two HBM traffic counter passes of the
+# profile_bench.sh TAG: full bench line, rocprofv3 kernel-trace stats and the two HBM traffic counter passes of the
 # headline workload (run on the GPU box; results under gpurun_out/prof_TAG/)
 set -o pipefail
 tag=$1

@@ -541,6 +541,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         if (target_given || !grows || target <= (1u << 20)) break;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+        if (const uint32_t pretend_mb = env_u32("RT_FREE_MEM_MB", 0)) free_b = (size_t)pretend_mb << 20; // for tests of this fallback
         const size_t held = ctx->capacity * (size_t)(2 * 48 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
         if (need <= (free_b + held) / 2) break;
         target /= 2;

@@ -175,6 +175,26 @@ def test_scheduling_knobs_do_not_change_results(rt, orc, gpu_ctx, monkeypatch, e
     ds.close()
 
 
+def test_refill_level_shrinks_to_fit_device_memory(rt, monkeypatch):
+    """Without RT_QUEUE_TARGET the refill level is halved until the queues fit into half of the free memory."""
+    hs = rt.HostScene("head", 1.0)
+    p = rt.default_params(640, 640, 8)  # 3.3 M camera samples: more than the 1 Mi rays the pretended memory allows
+    ctx_a = rt.Context(0)
+    ds_a = rt.DeviceScene(ctx_a, hs.desc)
+    big, st_big = ds_a.render(hs.camera, p)
+    ds_a.close()
+    ctx_a.close()
+    monkeypatch.setenv("RT_FREE_MEM_MB", "600")
+    ctx_b = rt.Context(0)  # a fresh context: its queues have not been allocated yet
+    ds_b = rt.DeviceScene(ctx_b, hs.desc)
+    small, st_small = ds_b.render(hs.camera, p)
+    ds_b.close()
+    ctx_b.close()
+    assert st_small.iterations > st_big.iterations
+    assert (st_small.rays_closest, st_small.rays_shadow) == (st_big.rays_closest, st_big.rays_shadow)
+    assert_radiance_close(small, big, rel=1e-5)
+
+
 def test_light_spectrum_is_linear(rt, gpu_ctx):
     hs = rt.HostScene("head", 1.0)
     d = hs.desc

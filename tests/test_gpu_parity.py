@@ -364,3 +364,22 @@ def test_full_size_render_properties_miku_1080p(rt, gpu_ctx):
     _, u8 = rt.resolve(a.cpu().numpy(), 2)
     assert np.array_equal(rgb.cpu().numpy(), u8)
     ds.close()
+
+
+def test_largest_frame_and_the_limit(rt, orc, gpu_ctx):
+    """2^24 pixels is the largest frame (the pixel index takes 24 bits of a path node): primary hits of such a frame
+    agree with the oracle bit for bit, one sample per pixel renders, and one more row is refused."""
+    W = H = 4096
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(W, H, 1)
+    gp, gt = ds.primary_hits(hs.camera, p)
+    cp, ct = orc.OracleScene(hs.desc, 1).primary_hits(hs.camera, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    acc, st = ds.render(hs.camera, p)
+    assert st.camera_samples == W * H and np.isfinite(acc).all() and acc.min() >= 0.0
+    assert (acc.reshape(-1, 3)[gp.reshape(-1) < 0] == 0).all()  # a primary ray that hits nothing adds nothing (black background)
+    with pytest.raises(rt.RtError, match="2\\^24") as e:
+        ds.render(hs.camera, rt.default_params(W, H + 1, 1))
+    assert e.value.code == rt.RT_ERR_INVALID
+    ds.close()

@@ -89,7 +89,7 @@ struct rt_context {
 
 struct rt_scene {
     rt_context *ctx = nullptr;
-    DevBuf<float4> nodes, tris, sph;
+    DevBuf<float4> nodes, tris, sph, loose;
     DevBuf<int2> sph_info, cyl_info;
     DevBuf<float> cyl, ltris;
     DevBuf<rt_material> mats;
@@ -426,23 +426,36 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     UP(s->mats, d->mats, d->n_mat, rt_material);
     UP(s->lights, lights.data(), d->n_light, DevLight);
     UP(s->ltris, d->light_tri_v, 9 * (size_t)d->n_light_tri, float);
-#undef UP
 
     s->dev.nodes = s->nodes.p; s->dev.tris = s->tris.p; s->dev.sph = s->sph.p; s->dev.sph_info = s->sph_info.p;
     s->dev.cyl = s->cyl.p; s->dev.cyl_info = s->cyl_info.p; s->dev.mats = s->mats.p; s->dev.lights = s->lights.p; s->dev.ltris = s->ltris.p;
     s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_orders = bvh.n_orders; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
     s->dev.n_light = d->n_light;
-    // boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box)
+    // Boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box),
+    // each the union of its triangles' boxes padded as the BVH pads them: a ray that misses all of them cannot hit a
+    // triangle of a big mesh.  Such rays are kept apart in the queues, and when the triangles outside the big meshes
+    // are few (RT_LOOSE_MAX, default 16; 0 = never) they scan those instead of walking the BVH.
     {
         struct MB { int count; float mn[3], mx[3]; };
         std::vector<MB> mbs;
-        for (int i = 0; i < d->n_obj; i++) {
+        std::vector<char> in_big(prim > 0 ? prim : 1, 0); // by primitive id
+        const bool classify = env_u32("RT_NO_HEAVY", 0) == 0;
+        for (int i = 0; i < d->n_obj && classify; i++) {
             const rt_object &ob = d->objects[i];
             if (ob.kind != RT_OBJ_MESH || ob.count < 64) continue;
             MB mb{ob.count, {1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
-            for (int f = 0; f < ob.count * 3; f++) {
-                const float *v = d->tri_v + 9 * (size_t)ob.first + 3 * (size_t)f;
-                for (int a = 0; a < 3; a++) { mb.mn[a] = std::min(mb.mn[a], v[a]); mb.mx[a] = std::max(mb.mx[a], v[a]); }
+            for (int f = 0; f < ob.count; f++) {
+                const float *v = d->tri_v + 9 * (size_t)(ob.first + f);
+                float mn[3], mx[3], ext = 0.0f, mag = 0.0f;
+                for (int a = 0; a < 3; a++) {
+                    mn[a] = std::min(std::min(v[a], v[3 + a]), v[6 + a]);
+                    mx[a] = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
+                    ext = std::max(ext, mx[a] - mn[a]);
+                    mag = std::max(mag, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+                }
+                const float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f; // same padding as the BVH leaves
+                for (int a = 0; a < 3; a++) { mb.mn[a] = std::min(mb.mn[a], mn[a] - pad); mb.mx[a] = std::max(mb.mx[a], mx[a] + pad); }
+                in_big[tri_prim[ob.first + f]] = 1;
             }
             mbs.push_back(mb);
         }
@@ -460,8 +473,29 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
                 }
             }
         }
-        if (env_u32("RT_NO_HEAVY", 0)) s->dev.n_heavy = 0;
+        // the loose triangles, taken from the BVH's triangle array (records: v0 + prim id, e1 + material, e2)
+        std::vector<std::pair<int, int>> by_prim; // (prim id, index into tris)
+        for (int i = 0; i < d->n_tri; i++) {
+            int32_t pid;
+            std::memcpy(&pid, &bvh.tris[12 * (size_t)i + 3], sizeof(pid));
+            if (!in_big[pid]) by_prim.emplace_back(pid, i);
+        }
+        std::sort(by_prim.begin(), by_prim.end());
+        std::vector<float> loose;
+        s->dev.n_loose = -1;
+        const size_t loose_max = env_u32_allow_zero("RT_LOOSE_MAX", 16);
+        if (loose_max > 0 && by_prim.size() <= loose_max) {
+            s->dev.n_loose = (int32_t)by_prim.size();
+            for (const auto &pi : by_prim) {
+                const float *rec = &bvh.tris[12 * (size_t)pi.second];
+                loose.insert(loose.end(), rec, rec + 12);
+                std::memcpy(&loose[loose.size() - 1], &pi.second, sizeof(int32_t));
+            }
+        }
+        UP(s->loose, loose.data(), loose.size() / 4, float4);
+        s->dev.loose = s->loose.p;
     }
+#undef UP
     for (const DevLight &L : lights) { s->n_disk_lights += L.kind == RT_LIGHT_DISK; s->n_point_lights += L.kind == RT_LIGHT_POINT; }
     *out = s;
     return RT_OK;
@@ -472,7 +506,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     s->nodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
-    s->mats.release(); s->lights.release(); s->ltris.release();
+    s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release();
     delete s;
     return RT_OK;
 }

@@ -128,10 +128,15 @@ struct DevScene {
     const DevLight *lights;
     const float *ltris;     // 9 floats per light triangle
     int32_t n_nodes, n_top, n_orders, n_tri, n_sph, n_cyl, n_light;
-    // Boxes around the big meshes.  A ray that touches one is expected to walk deep into the BVH ("heavy"), the others
-    // only meet the few large triangles around them; the queues keep the two kinds apart so that the lanes of a wave
-    // have similar trip counts.  Purely a scheduling hint: results do not depend on it.
+    // Padded boxes around the big meshes.  A ray that touches one is expected to walk deep into the BVH ("heavy"), the
+    // others ("light") can only meet triangles outside the big meshes; the queues keep the two kinds apart so that the
+    // lanes of a wave have similar trip counts.  The test (ray_is_heavy) is conservative like the BVH's box test.
     int32_t n_heavy;
+    // The triangles outside the big meshes, in primitive-id order, when they are few (n_loose >= 0; -1 = not in use):
+    // (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, index into tris).  A light ray is tested against all of them in a
+    // loop the whole wave runs together (the reference's own scan of the world list, hitable.rs:44-50) instead of walking the BVH.
+    const float4 *loose;
+    int32_t n_loose;
     float heavy_min[4][3];
     float heavy_max[4][3];
 };
@@ -148,7 +153,7 @@ __device__ __forceinline__ bool ray_is_heavy(const DevScene &sc, F3 o, F3 d, flo
         float z0 = (sc.heavy_min[k][2] - o.z) * iz, z1 = (sc.heavy_max[k][2] - o.z) * iz;
         float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
         float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
-        heavy |= tn <= tf;
+        heavy |= tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f); // widened exit like the BVH's box test: never misses a mesh the ray can hit
     }
     return heavy;
 }
@@ -393,12 +398,33 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
     return best;
 }
 
+// The loose triangles, one after the other, for a ray that misses the boxes of all big meshes.  The loop is the same for
+// every lane of the wave (no divergent walk) and the triangle data is uniform, so the loads are scalar.
+template <bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_tris) {
+    TriHit best{t_max, -1, -1};
+    for (int k = 0; k < sc.n_loose; k++) {
+        const float4 a = sc.loose[3 * k], b = sc.loose[3 * k + 1], c = sc.loose[3 * k + 2];
+        if (COUNT) (*n_tris)++;
+        float t;
+        if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
+            const int prim = __float_as_int(a.w);
+            if (ANY_HIT || t < best.t || (t == best.t && prim > best.prim)) {
+                best.t = t; best.tri = __float_as_int(c.w); best.prim = prim;
+            }
+            if (ANY_HIT) break;
+        }
+    }
+    return best;
+}
+
 // world.objects.hit (hitable.rs:35-62): triangles through the BVH, then spheres and cylinders in order.  A sphere or
 // cylinder needs t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.
-template <bool COUNT, bool USE_LDS = false, bool POSTPONE = false>
+template <bool COUNT, bool USE_LDS = false, bool POSTPONE = false, bool LOOSE = false>
 __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max, float *t_out,
                                           int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
-    TriHit th = bvh_traverse<false, COUNT, USE_LDS, POSTPONE>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    TriHit th = LOOSE ? loose_traverse<false, COUNT>(sc, o, d, t_min, t_max, n_tris)
+                      : bvh_traverse<false, COUNT, USE_LDS, POSTPONE>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
     float closest = th.t;
     int code = th.tri >= 0 ? hit_code(HIT_KIND_TRI, th.tri) : HIT_NONE;
     int prim = th.prim;
@@ -417,7 +443,7 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)
-template <bool COUNT, bool USE_LDS = false>
+template <bool COUNT, bool USE_LDS = false, bool LOOSE = false>
 __device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     for (int i = 0; i < sc.n_sph; i++) {
@@ -429,7 +455,8 @@ __device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 
         int kind;
         if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind)) return true;
     }
-    TriHit th = bvh_traverse<true, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+    TriHit th = LOOSE ? loose_traverse<true, COUNT>(sc, o, d, t_min, t_max, n_tris)
+                      : bvh_traverse<true, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
     return th.tri >= 0;
 }
 

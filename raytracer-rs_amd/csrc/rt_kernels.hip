@@ -289,14 +289,16 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     // the ray's loads are in flight while the top of the tree is copied into LDS
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (il < n_seg) { a = in.a[i]; b = in.b[i]; }
-    if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+    const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0; // light rays scan the few triangles outside the big meshes
+    if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
     if (il >= n_seg) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     float t_obj;
     int code, prim;
     uint32_t nn = 0, nt = 0;
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
-    if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     hit[i] = make_float2(t_obj, __int_as_float(code));
     if (COUNT) {
@@ -643,11 +645,13 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     float4 a = make_float4(0, 0, 0, 0), b = a;
     float2 c = make_float2(0, 0);
     if (il < n) { a = sh.a[i]; b = sh.b[i]; c = sh.c[i]; }
-    if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+    const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0;
+    if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
     if (il >= n) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     uint32_t nn = 0, nt = 0;
-    bool occ = world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    const bool occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
+                           : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);

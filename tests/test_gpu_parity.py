@@ -151,7 +151,7 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
     ds.close()
 
 
-KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"},
+KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"},
          {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"}]
 
 
@@ -168,6 +168,23 @@ def test_scheduling_knobs_do_not_change_results(rt, orc, gpu_ctx, monkeypatch, e
     gp, gt = ds.primary_hits(hs.camera, p)
     cp, ct = osc.primary_hits(hs.camera, p)
     assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    ga, gs = ds.render(hs.camera, p)
+    ca, cs = osc.render(hs.camera, p)
+    assert_radiance_close(ga, ca)
+    assert gs.camera_samples == W * H * spp
+    ds.close()
+
+
+@pytest.mark.parametrize("scene,shader_name", [("whitted", "SHADER_WHITTED"), ("cornell", "SHADER_MIS"), ("mis_test", "SHADER_MIS"), ("head", "SHADER_MIS")])
+def test_scan_of_loose_triangles_matches_the_walk(rt, orc, gpu_ctx, monkeypatch, scene, shader_name):
+    """Rays that miss the boxes of all big meshes scan the triangles outside them instead of walking the BVH when those
+    are few; with the limit raised every scene's loose triangles qualify (28 in the Whitted scene, all of mis_test)."""
+    monkeypatch.setenv("RT_LOOSE_MAX", "4096")
+    W, H, spp = 64, 48, 2
+    hs = rt.HostScene(scene, W / H)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    osc = orc.OracleScene(hs.desc, 1)
+    p = rt.default_params(W, H, spp, shader=getattr(rt, shader_name))
     ga, gs = ds.render(hs.camera, p)
     ca, cs = osc.render(hs.camera, p)
     assert_radiance_close(ga, ca)

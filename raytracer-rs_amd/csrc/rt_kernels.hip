@@ -282,13 +282,15 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     extern __shared__ float4 lds_nodes[];
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
-    const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
-    if (bx * BLOCK >= n_seg) return;
     const uint32_t il = bx * BLOCK + threadIdx.x;
     const uint32_t i = seg * seg_capacity + il;
-    // the ray's loads are in flight while the top of the tree is copied into LDS
-    float4 a = make_float4(0, 0, 0, 0), b = a;
-    if (il < n_seg) { a = in.a[i]; b = in.b[i]; }
+    // The ray is fetched before the segment's fill count is known (a wave lives about 2 us, and waiting for the count
+    // first adds a round trip to that): the slot exists whether it is filled or not.  The loads are then in flight while
+    // the top of the tree is copied into LDS.
+    const uint32_t i_safe = seg * seg_capacity + min(il, seg_capacity - 1u);
+    const float4 a = in.a[i_safe], b = in.b[i_safe];
+    const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
+    if (bx * BLOCK >= n_seg) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0; // light rays scan the few triangles outside the big meshes
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
     if (il >= n_seg) return;
@@ -405,10 +407,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     __shared__ BlockAppendSeg sm;
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    const uint32_t il = bx * BLOCK + threadIdx.x;
+    // node and hit record are fetched before the fill count is known, like the ray of k_extend
+    const uint32_t i = seg * seg_capacity + min(il, seg_capacity - 1u);
+    const Node nd_early = load_node(in, i);
+    const float2 h_early = hit[i];
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     if (bx * BLOCK >= n_seg) return;
-    const uint32_t il = bx * BLOCK + threadIdx.x;
-    const uint32_t i = seg * seg_capacity + il;
     const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
 
     bool have0 = false, have1 = false, have_s = false;
@@ -421,8 +426,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     uint32_t vis_pk = 0, vis_nk = 0;
 
     if (il < n_seg) {
-        Node nd = load_node(in, i);
-        const float2 h = hit[i];
+        const Node nd = nd_early;
+        const float2 h = h_early;
         const float t_obj = h.x;
         const int code = __float_as_int(h.y);
         // world.lights.hit(r) (shader.rs:99): tested here, where every lane of the wave is busy, not in the traversal kernel
@@ -638,13 +643,13 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     extern __shared__ float4 lds_nodes[];
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    const uint32_t il = bx * BLOCK + threadIdx.x;
+    // fetched before the fill count is known, like the ray of k_extend
+    const uint32_t i = seg * shadow_seg_capacity + min(il, shadow_seg_capacity - 1u);
+    const float4 a = sh.a[i], b = sh.b[i];
+    const float2 c = sh.c[i];
     const uint32_t n = min(ctl->seg_shadow_cur[seg], shadow_seg_capacity);
     if (bx * BLOCK >= n) return;
-    const uint32_t il = bx * BLOCK + threadIdx.x;
-    const uint32_t i = seg * shadow_seg_capacity + il;
-    float4 a = make_float4(0, 0, 0, 0), b = a;
-    float2 c = make_float2(0, 0);
-    if (il < n) { a = sh.a[i]; b = sh.b[i]; c = sh.c[i]; }
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0;
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
     if (il >= n) return;

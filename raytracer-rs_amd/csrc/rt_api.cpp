@@ -617,6 +617,10 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         const bool overlap = env_u32_allow_zero("RT_OVERLAP", 1) != 0;
         hipStream_t shadow_stream = overlap ? ctx->stream2 : ctx->stream;
         bool shadow_pending = false;
+        const bool dump_iter = std::getenv("RT_DUMP_ITER") != nullptr;
+        // paths left when the staged iterations hand over to k_tail (RT_TAIL, 0 = never); not for the Whitted shader
+        // (several shadow rays per node) nor for work-counting calls
+        const uint32_t tail_limit = (p->shader == RT_SHADER_WHITTED || count_work) ? 0u : env_u32_allow_zero("RT_TAIL", 1u << 18);
         for (;;) {
             if (shadow_pending && overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->shadow_done, 0)); // k_plan rewrites the counts k_shadow reads
             shadow_pending = false;
@@ -626,6 +630,10 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
             if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
+            if (dump_iter) // development aid: the population and the wall clock at every iteration
+                std::fprintf(stderr, "[rt] %8.3f ms: %u nodes carried in, %u camera rays to add, shadow rays <= %u + %u per segment\n",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c.n_alive, c.n_new, c.max_sh_light,
+                             c.max_sh_heavy);
             // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
             if (c.max_sh_light || c.max_sh_heavy) {
                 ShadowQueue filled{ctx->sa[scur ^ 1].p, ctx->sb[scur ^ 1].p, ctx->sc2[scur ^ 1].p};
@@ -655,6 +663,18 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             const uint32_t fresh = ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * 256u;
             const uint32_t light_threads = std::min(seg_capacity, c.max_in_light + fresh);
             const uint32_t heavy_threads = s->dev.n_heavy ? std::min(seg_capacity, c.max_in_heavy + fresh) : c.max_in_heavy;
+            if (tail_limit && c.n_new == 0 && c.cursor == c.total && c.n_alive <= tail_limit) {
+                // the last few paths: one launch follows each of them to its end (see k_tail)
+                timer.begin(0);
+                launch_tail(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->planes.p, (uint32_t)plane_stride, light_threads, heavy_threads);
+                timer.end();
+                st.launches_extend++;
+                hipError_t le = hipGetLastError();
+                if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+                cur ^= 1;
+                scur ^= 1;
+                continue;
+            }
             timer.begin(0);
             launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, light_threads, heavy_threads, count_work);
             timer.end();

@@ -87,6 +87,9 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
                   const float2 *hit, ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads);
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
                    uint32_t light_threads, uint32_t heavy_threads, bool count);
+// the end of a call: every node of the current queue is followed to the end of its path by one thread (MIS and path shaders)
+void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes,
+                 uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads);
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels);
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t);
 void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const float *planes, float *accum_rgb, uint32_t n_pixels);

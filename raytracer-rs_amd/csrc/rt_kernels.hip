@@ -397,6 +397,125 @@ __device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst
     return true;
 }
 
+// What shading one node yields: up to two children, one next-event shadow ray (or, for the Whitted shader, the surface
+// point whose light samples the caller expands).  Emission and the 0 * inf of a miss are added to the pixel here.
+struct ShadeResult {
+    bool have0 = false, have1 = false, have_s = false;
+    Node c0, c1;
+    F3 s_o = {0.0f, 0.0f, 0.0f}, s_d = {0.0f, 0.0f, 1.0f}, s_c = {0.0f, 0.0f, 0.0f};
+    uint32_t s_pixel = 0;
+    // Whitted's LightList::visible needs several shadow rays per surface point; they are produced after the main body
+    bool vis_pending = false;
+    F3 vis_p, vis_n, vis_w;
+    uint32_t vis_pk = 0, vis_nk = 0;
+};
+
+template <int SHADER>
+__device__ __forceinline__ void shade_node(const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels, const Node &nd, float2 h,
+                                           ShadeResult &r) {
+    const float t_obj = h.x;
+    const int code = __float_as_int(h.y);
+    // world.lights.hit(r) (shader.rs:99): tested here, where every lane of the wave is busy, not in the traversal kernel
+    float t_l = 0.0f;
+    const int li = lights_hit(sc, nd.o, nd.d, rc.t_min, rc.t_max, &t_l);
+    const uint32_t pixel = nd.meta & 0xFFFFFFu, depth = (nd.meta >> 24) & 63u, root = (nd.meta >> 30) & 1u;
+
+    // weight of this node: MIS divides by (light pdf + BSDF pdf) of the ray that led here (material.rs:465-467)
+    F3 beta = nd.w;
+    if (SHADER == RT_SHADER_MIS && !root) {
+        float l_pdf = li >= 0 ? light_pdf_with_t(sc.lights[li], nd.d, true, t_l) : RTD_ZERO; // LightList::pdf, light.rs:399-405
+        beta = div_w(nd.w, l_pdf + nd.b_pdf);
+    }
+    const bool obj = code != HIT_NONE;
+    const bool light_wins = li >= 0 && (!obj || !(t_l > t_obj)); // shader.rs:101,108-112
+    if (light_wins) {
+        const DevLight &L = sc.lights[li];
+        add_pixel(planes, n_pixels, tiled_index(rc, pixel), mul_v(beta, f3(L.sx, L.sy, L.sz)));
+    } else if (!obj) {
+        if (!all_finite(beta)) add_pixel(planes, n_pixels, tiled_index(rc, pixel), beta * 0.0f); // 0 * inf, 0 * NaN of the recursive form
+    } else {
+        const F3 p = nd.o + t_obj * nd.d; // ray.rs:9-11
+        F3 n;
+        int mat_id;
+        surface_at(sc, code, p, &n, &mat_id);
+        const rt_material m = sc.mats[mat_id];
+        const uint32_t pk = pixel_key(rc.seed, pixel);
+
+        if (SHADER == RT_SHADER_MIS) {
+            F3 sd;
+            if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+                F3 brdf;
+                float pdf;
+                mat_brdf_pdf(m, nd.d, sd, n, rc.t_min, &brdf, &pdf);
+                F3 w = mul_v(beta, brdf);
+                if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                    r.have0 = true;
+                    r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = pdf;
+                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
+                    r.c0.nk = child_node_key(nd.nk, 0u);
+                }
+            }
+            if (m.kind == RT_MAT_MICROFACET) { // the diffuse lobe of material.rs:416-438
+                Stream st(pk, nd.nk, P_DIFFUSE);
+                F3 dd = unit_vec_on_sphere(st);
+                if (dot(dd, n) < 0.0f) dd = -dd;
+                F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
+                F3 f = fresnel_schlick(dd, n, f0);
+                F3 kd = (f3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
+                F3 w = mul_v(beta, mul_v(kd, albedo_of(m) * (1.0f / RTD_PI)));
+                uint32_t dmin = (uint32_t)max(rc.max_depth - 6, 0); // depth.max(34) for the reference's 40
+                uint32_t d1 = max(depth, dmin) + 1u;
+                if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
+                    r.have1 = true;
+                    r.c1.o = p; r.c1.d = dd; r.c1.w = w; r.c1.b_pdf = 1.0f / RTD_PI;
+                    r.c1.meta = make_meta(pixel, d1, 0u);
+                    r.c1.nk = child_node_key(nd.nk, 1u);
+                }
+            }
+            F3 ldir, radiance;
+            float p_l;
+            if (nee_sample(sc, rc, p, n, pk, nd.nk, &ldir, &radiance, &p_l)) { // material.rs:441-447, 473-480
+                F3 brdf;
+                float pdf;
+                mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
+                F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
+                F3 c = mul_v(beta, direct);
+                if (!is_black(c)) {
+                    r.have_s = true;
+                    r.s_o = p; r.s_d = ldir; r.s_c = c; r.s_pixel = tiled_index(rc, pixel);
+                }
+            }
+        } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
+            F3 sd;
+            if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+                F3 w = mul_v(beta, mat_attenuation(m));
+                if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                    r.have0 = true;
+                    r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = 1.0f;
+                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
+                    r.c0.nk = child_node_key(nd.nk, 0u);
+                }
+            }
+        } else { // RT_SHADER_WHITTED, shader.rs:32-45
+            F3 sd;
+            bool scat = (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) && mat_scatter_specular(m, nd.d, n, rc.t_min, &sd);
+            F3 w = mul_v(beta, mat_attenuation(m));
+            if (scat) {
+                if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
+                    r.have0 = true;
+                    r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = 1.0f;
+                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
+                    r.c0.nk = child_node_key(nd.nk, 0u);
+                }
+            } else if (!is_black(w)) {
+                r.vis_pending = true;
+                r.vis_p = p; r.vis_n = n; r.vis_w = w; r.vis_pk = pk; r.vis_nk = nd.nk;
+                r.s_pixel = tiled_index(rc, pixel);
+            }
+        }
+    }
+}
+
 // ---- k_shade ---------------------------------------------------------------------------------------------------------
 // grid (blocks, RT_NSEG) like k_extend.  Children go to segment (bx + s) % RT_NSEG of the next queue, which spreads
 // every segment's offspring over all segments and keeps them level.
@@ -416,120 +535,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     if (bx * BLOCK >= n_seg) return;
     const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
 
-    bool have0 = false, have1 = false, have_s = false;
-    Node c0, c1;
-    F3 s_o = f3(0.0f, 0.0f, 0.0f), s_d = f3(0.0f, 0.0f, 1.0f), s_c = f3(0.0f, 0.0f, 0.0f);
-    uint32_t s_pixel = 0;
-    // Whitted's LightList::visible needs several shadow rays per surface point; they are produced after the main body
-    bool vis_pending = false;
-    F3 vis_p, vis_n, vis_w;
-    uint32_t vis_pk = 0, vis_nk = 0;
-
-    if (il < n_seg) {
-        const Node nd = nd_early;
-        const float2 h = h_early;
-        const float t_obj = h.x;
-        const int code = __float_as_int(h.y);
-        // world.lights.hit(r) (shader.rs:99): tested here, where every lane of the wave is busy, not in the traversal kernel
-        float t_l = 0.0f;
-        const int li = lights_hit(sc, nd.o, nd.d, rc.t_min, rc.t_max, &t_l);
-        const uint32_t pixel = nd.meta & 0xFFFFFFu, depth = (nd.meta >> 24) & 63u, root = (nd.meta >> 30) & 1u;
-
-        // weight of this node: MIS divides by (light pdf + BSDF pdf) of the ray that led here (material.rs:465-467)
-        F3 beta = nd.w;
-        if (SHADER == RT_SHADER_MIS && !root) {
-            float l_pdf = li >= 0 ? light_pdf_with_t(sc.lights[li], nd.d, true, t_l) : RTD_ZERO; // LightList::pdf, light.rs:399-405
-            beta = div_w(nd.w, l_pdf + nd.b_pdf);
-        }
-        const bool obj = code != HIT_NONE;
-        const bool light_wins = li >= 0 && (!obj || !(t_l > t_obj)); // shader.rs:101,108-112
-        if (light_wins) {
-            const DevLight &L = sc.lights[li];
-            add_pixel(planes, n_pixels, tiled_index(rc, pixel), mul_v(beta, f3(L.sx, L.sy, L.sz)));
-        } else if (!obj) {
-            if (!all_finite(beta)) add_pixel(planes, n_pixels, tiled_index(rc, pixel), beta * 0.0f); // 0 * inf, 0 * NaN of the recursive form
-        } else {
-            const F3 p = nd.o + t_obj * nd.d; // ray.rs:9-11
-            F3 n;
-            int mat_id;
-            surface_at(sc, code, p, &n, &mat_id);
-            const rt_material m = sc.mats[mat_id];
-            const uint32_t pk = pixel_key(rc.seed, pixel);
-
-            if (SHADER == RT_SHADER_MIS) {
-                F3 sd;
-                if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
-                    F3 brdf;
-                    float pdf;
-                    mat_brdf_pdf(m, nd.d, sd, n, rc.t_min, &brdf, &pdf);
-                    F3 w = mul_v(beta, brdf);
-                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
-                        have0 = true;
-                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = pdf;
-                        c0.meta = make_meta(pixel, depth + 1u, 0u);
-                        c0.nk = child_node_key(nd.nk, 0u);
-                    }
-                }
-                if (m.kind == RT_MAT_MICROFACET) { // the diffuse lobe of material.rs:416-438
-                    Stream st(pk, nd.nk, P_DIFFUSE);
-                    F3 dd = unit_vec_on_sphere(st);
-                    if (dot(dd, n) < 0.0f) dd = -dd;
-                    F3 f0 = lerp(f0_of(m), albedo_of(m), m.metallic);
-                    F3 f = fresnel_schlick(dd, n, f0);
-                    F3 kd = (f3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
-                    F3 w = mul_v(beta, mul_v(kd, albedo_of(m) * (1.0f / RTD_PI)));
-                    uint32_t dmin = (uint32_t)max(rc.max_depth - 6, 0); // depth.max(34) for the reference's 40
-                    uint32_t d1 = max(depth, dmin) + 1u;
-                    if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
-                        have1 = true;
-                        c1.o = p; c1.d = dd; c1.w = w; c1.b_pdf = 1.0f / RTD_PI;
-                        c1.meta = make_meta(pixel, d1, 0u);
-                        c1.nk = child_node_key(nd.nk, 1u);
-                    }
-                }
-                F3 ldir, radiance;
-                float p_l;
-                if (nee_sample(sc, rc, p, n, pk, nd.nk, &ldir, &radiance, &p_l)) { // material.rs:441-447, 473-480
-                    F3 brdf;
-                    float pdf;
-                    mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
-                    F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
-                    F3 c = mul_v(beta, direct);
-                    if (!is_black(c)) {
-                        have_s = true;
-                        s_o = p; s_d = ldir; s_c = c; s_pixel = tiled_index(rc, pixel);
-                    }
-                }
-            } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
-                F3 sd;
-                if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
-                    F3 w = mul_v(beta, mat_attenuation(m));
-                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
-                        have0 = true;
-                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = 1.0f;
-                        c0.meta = make_meta(pixel, depth + 1u, 0u);
-                        c0.nk = child_node_key(nd.nk, 0u);
-                    }
-                }
-            } else { // RT_SHADER_WHITTED, shader.rs:32-45
-                F3 sd;
-                bool scat = (m.kind == RT_MAT_METAL || m.kind == RT_MAT_DIELECTRIC) && mat_scatter_specular(m, nd.d, n, rc.t_min, &sd);
-                F3 w = mul_v(beta, mat_attenuation(m));
-                if (scat) {
-                    if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
-                        have0 = true;
-                        c0.o = p; c0.d = sd; c0.w = w; c0.b_pdf = 1.0f;
-                        c0.meta = make_meta(pixel, depth + 1u, 0u);
-                        c0.nk = child_node_key(nd.nk, 0u);
-                    }
-                } else if (!is_black(w)) {
-                    vis_pending = true;
-                    vis_p = p; vis_n = n; vis_w = w; vis_pk = pk; vis_nk = nd.nk;
-                    s_pixel = tiled_index(rc, pixel);
-                }
-            }
-        }
-    }
+    ShadeResult r;
+    if (il < n_seg) shade_node<SHADER>(sc, rc, planes, n_pixels, nd_early, h_early, r);
+    const bool have0 = r.have0, have1 = r.have1, have_s = r.have_s, vis_pending = r.vis_pending;
+    const Node &c0 = r.c0, &c1 = r.c1;
+    const F3 s_o = r.s_o, s_d = r.s_d, s_c = r.s_c, vis_p = r.vis_p, vis_n = r.vis_n, vis_w = r.vis_w;
+    const uint32_t s_pixel = r.s_pixel, vis_pk = r.vis_pk, vis_nk = r.vis_nk;
 
     // ---- compaction: children into the next queue, shadow rays into the shadow queue, light and heavy rays apart
     const bool heavy0 = have0 && ray_is_heavy(sc, c0.o, c0.d, rc.t_min, rc.t_max);
@@ -664,6 +675,56 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     }
 }
 
+// ---- k_tail ----------------------------------------------------------------------------------------------------------
+// The end of a call: few paths are left and every wavefront iteration (plan, extend, shade, shadow, a host round trip)
+// costs its fixed ~90 us whatever it carries, for up to max_depth more iterations.  Here one thread takes one node of
+// the current queue and follows the path to its end: closest hit, shading, the occlusion query of its shadow ray, next
+// bounce.  Second children (Microfacet: they start at depth >= max_depth - 5, so at most six are ever pending) wait on
+// a small stack of the thread; should it overflow they go to the next queue, which a further launch of this kernel
+// takes up.  Same random numbers, same arithmetic as the staged kernels; only the order of the atomic adds differs.
+template <int SHADER>
+__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes, uint32_t n_pixels,
+                                                uint32_t seg_capacity, uint32_t heavy_blocks) {
+    uint32_t seg, bx;
+    decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
+    const uint32_t il = bx * BLOCK + threadIdx.x;
+    if (il >= n_seg) return;
+    Node nd = load_node(in, seg * seg_capacity + il);
+    const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
+    uint32_t more_closest = 0, shadows = 0;
+    Node pending[6];
+    int n_pending = 0;
+    for (;;) { // ends: a child is deeper than its parent and needs depth <= max_depth
+        float t_obj;
+        int code, prim;
+        uint32_t nn = 0, nt = 0;
+        // (the plain walk: with the top of the tree in LDS and the scan of the loose triangles this kernel was measured no faster)
+        world_hit<false>(sc, nullptr, nd.o, nd.d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+        ShadeResult r;
+        shade_node<SHADER>(sc, rc, planes, n_pixels, nd, make_float2(t_obj, __int_as_float(code)), r);
+        if (r.have_s) {
+            shadows++;
+            if (!world_occluded<false>(sc, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
+        }
+        if (r.have1) {
+            if (n_pending < 6) pending[n_pending++] = r.c1;
+            else {
+                const uint32_t oseg = ray_segment(ray_is_heavy(sc, r.c1.o, r.c1.d, rc.t_min, rc.t_max), oseg_l);
+                const uint32_t slot = atomicAdd(&ctl->seg_out[oseg].v, 1u);
+                if (slot < seg_capacity) store_node(out, oseg * seg_capacity + slot, r.c1); else ctl->h.overflow = 1;
+            }
+        }
+        if (r.have0) nd = r.c0;
+        else if (n_pending > 0) nd = pending[--n_pending];
+        else break;
+        more_closest++;
+    }
+    // the first ray of every path is counted by k_plan with the queue, the others here
+    if (more_closest) atomicAdd(&ctl->h.rays_closest, (unsigned long long)more_closest);
+    if (shadows) atomicAdd(&ctl->h.rays_shadow, (unsigned long long)shadows);
+}
+
 // ---- normal shader (shader.rs:7-13): no queues, one thread per pixel looping over its samples ---------------------------
 __global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderConst rc, float *planes, uint32_t n_pixels) {
     const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
@@ -786,6 +847,16 @@ void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
     else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
     else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+}
+
+void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes,
+                 uint32_t n_pixels, uint32_t light_threads, uint32_t heavy_threads) {
+    uint32_t hb;
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    if (!grid) return;
+    dim3 g(grid), b(BLOCK);
+    if (shader == RT_SHADER_MIS) hipLaunchKernelGGL(k_tail<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
+    else hipLaunchKernelGGL(k_tail<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
 }
 
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels) {

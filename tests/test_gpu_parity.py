@@ -151,7 +151,7 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
     ds.close()
 
 
-KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"},
+KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
          {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"}]
 
 
@@ -189,6 +189,24 @@ def test_scan_of_loose_triangles_matches_the_walk(rt, orc, gpu_ctx, monkeypatch,
     ca, cs = osc.render(hs.camera, p)
     assert_radiance_close(ga, ca)
     assert gs.camera_samples == W * H * spp
+    ds.close()
+
+
+def test_tail_kernel_traces_the_same_rays(rt, gpu_ctx, monkeypatch):
+    """The last paths of a call are followed to their end by one kernel launch instead of one wavefront iteration per
+    bounce (RT_TAIL = population at which that starts, 0 = never): same rays, same image, fewer iterations."""
+    hs = rt.HostScene("utah", 16 / 9)  # Microfacet teapot: second children wait on the tail kernel's stack
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(160, 90, 8)
+    results = []
+    for tail in ("0", "2000", "100000000"):  # never, for the last 2000 paths, from the first bounce on
+        monkeypatch.setenv("RT_TAIL", tail)
+        results.append(ds.render(hs.camera, p))
+    (a0, s0), (a1, s1), (a2, s2) = results
+    for a, s in ((a1, s1), (a2, s2)):
+        assert (s.rays_closest, s.rays_shadow, s.camera_samples) == (s0.rays_closest, s0.rays_shadow, s0.camera_samples)
+        assert_radiance_close(a, a0, rel=1e-5)
+    assert s2.iterations < s1.iterations < s0.iterations
     ds.close()
 
 

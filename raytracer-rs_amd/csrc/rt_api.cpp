@@ -550,13 +550,14 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
 
-    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`.  The default keeps 32 Mi rays in
-    // flight (measured: 8 Mi -> 32 Mi is 3-8 % faster, the few long walks of a launch overlap with more short ones);
-    // that is about 50 GB of queues, so without an explicit RT_QUEUE_TARGET the level is halved until the queues fit
+    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`.  The default keeps 64 Mi rays in
+    // flight (measured: 8 Mi -> 32 Mi is 3-8 % faster, 32 Mi -> 64 Mi another 2-3 %: fewer iterations, and the few long
+    // walks of a launch overlap with more short ones);
+    // that is about 100 GB of queues, so without an explicit RT_QUEUE_TARGET the level is halved until the queues fit
     // into half of the free device memory.
     const char *target_env = std::getenv("RT_QUEUE_TARGET");
     const bool target_given = target_env && *target_env;
-    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 25);
+    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 26);
     // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
     // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
     uint32_t per_node = 1;

@@ -32,6 +32,44 @@ WORKLOADS = {
 }
 
 
+def launch_ranks(n: int) -> int:
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment), same arguments."""
+    import socket
+    import subprocess
+
+    import torch  # counting devices does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def source_id() -> str:
+    """Hash of the sources the device library is built from: ties a cached counter file to the build it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer-rs_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +83,14 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path")
     args = ap.parse_args()
+
+    # --gpus N without a launcher around this script: start the N ranks here, before this process touches torch or HIP
+    # (a process that has initialised the GPU must not be replaced or forked), and relay rank 0's JSON line.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}", file=sys.stderr)
+        return 2
 
     # The renderer overlaps two streams, torch and RCCL bring theirs; HIP's default of 4 hardware queues per process
     # makes streams share queues (and lose the overlap) once RCCL is up.  Must be set before the HIP runtime starts.
@@ -87,6 +133,7 @@ def main() -> int:
     shader = {"mis": rt.SHADER_MIS, "whitted": rt.SHADER_WHITTED, "path": rt.SHADER_PATH, "normal": rt.SHADER_NORMAL}[shader_name]
 
     hs = rt.HostScene(scene_name, W / H)
+    t_cold = time.perf_counter()
     ctx = rt.Context(local_rank)
     t0 = time.perf_counter()
     ds = rt.DeviceScene(ctx, hs.desc)
@@ -100,14 +147,23 @@ def main() -> int:
     hip = rt.hip_lib()
 
     def step():
+        # Three streams take part: torch's current stream (zeroing, RCCL), and the context's stream (rt_render and
+        # rt_resolve_device, both of which return with their work complete).  Each hand-over is a full synchronisation
+        # of the producing stream: render -> reduce -> resolve, one after the other.
         accum.zero_()
-        torch.cuda.synchronize()  # accum is zeroed on torch's stream, rt_render works on the context's stream
+        torch.cuda.current_stream().synchronize()
         st = ds.render_device(hs.camera, params, accum.data_ptr())
-        rt.reduce_accum(accum, dst=0)
+        if use_dist:
+            rt.reduce_accum(accum, dst=0)
+            torch.cuda.current_stream().synchronize()  # the reduce runs on torch's stream, the resolve on the context's
         if rank == 0:
             rc = hip.rt_resolve_device(ctx._h, accum.data_ptr(), W * H, spp, rgb8.data_ptr())
             assert rc == 0, hip.rt_last_error()
         return st
+
+    # cold start: context, scene build + upload, and the first render with its queue allocation, on this rank
+    st_cold = step()
+    cold_ms = (time.perf_counter() - t_cold) * 1e3
 
     def fence():
         if use_dist:
@@ -170,13 +226,21 @@ def main() -> int:
             "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node, sum(s.launches_shade for s in stats), sum(s.ms_shade for s in stats)),
             "k_shadow": (shadow, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
         }
-        traffic_file = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        # HBM traffic from the PMC counters is not collected by this run: it comes from the committed counter passes of
+        # this same command, and only when they were taken on a library built from the sources in this tree
+        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         measured_traffic = {}
+        traffic_note = "no counter file"
         if os.path.exists(traffic_file):
             with open(traffic_file) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and not args.spp:
+            if tj.get("workload") != args.workload or args.spp:
+                traffic_note = "counter file is for another workload"
+            elif tj.get("source_id") != source_id():
+                traffic_note = "counter file was taken on another build"
+            else:
                 measured_traffic = tj.get("bytes_per_launch", {})
+                traffic_note = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command on this build)"
         kernels = {}
         for name, (units, bpu, launches, ms) in per_unit.items():
             if launches and ms > 0:
@@ -212,6 +276,7 @@ def main() -> int:
                     "bytes_per_ray": round(40 + geo_b, 1), "flops_per_ray": round(geo_f, 1),
                     "achieved_GBps": round(frame_b / sec / 1e9, 1), "achieved_TFLOPs": round(frame_f / sec / 1e12, 2),
                     "valu_peak_TFLOPs": 78.65, "valu_frac": round(frame_f / sec / 1e12 / 78.65, 4)}
+            roofline["traffic_source"] = traffic_note
             roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)
             roofline["nodes_per_ray"] = round(nodes_per_ray, 2)
             roofline["tris_per_ray"] = round(tris_per_ray, 2)
@@ -220,6 +285,7 @@ def main() -> int:
 
         # ---- CPU baseline: the oracle (a restatement of the reference, not the Rust binary) on a bounded sample
         cpu = None
+        pruned = None
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle_py as orc
@@ -227,15 +293,14 @@ def main() -> int:
             osc = orc.OracleScene(hs.desc, 1)
             threads = min(orc.num_threads(), int(os.environ.get("OMP_NUM_THREADS", "16")))
             # calibrate on a coarse frame, then size the sample (same scene, camera and frame, first k samples per pixel
-            # of a sub-sampled frame) for about cpu_seconds of work
+            # of a sub-sampled frame) for about cpu_seconds of work on all threads
             cw, ch = max(8, W // 8), max(8, H // 8)
             pp = rt.default_params(cw, ch, spp, shader=shader, seed=1)
             pp.spp_begin, pp.spp_end = 0, 1
             t0 = time.perf_counter()
             _, cs = osc.render(hs.camera, pp, threads=threads)
             dt = max(time.perf_counter() - t0, 1e-3)
-            rate = (cs.rays_closest + cs.rays_shadow) / dt
-            scale = max(1.0, args.cpu_seconds / dt)
+            scale = max(1.0, 0.6 * args.cpu_seconds / dt)
             # grow the frame first (up to the full frame), then the number of samples
             f = min(8.0, scale ** 0.5)
             sw, sh_ = min(W, int(cw * f)), min(H, int(ch * f))
@@ -246,18 +311,37 @@ def main() -> int:
             _, cs = osc.render(hs.camera, pp, threads=threads)
             dt = time.perf_counter() - t0
             cpu_rays = cs.rays_closest + cs.rays_shadow
+            # the reference itself is single-threaded (src/bin/main.rs): the same frame, fewer samples, on one thread
+            k1 = max(1, int(round(k * 0.4 * args.cpu_seconds / max(dt, 1e-3) / max(1, threads))))
+            p1 = rt.default_params(sw, sh_, spp, shader=shader, seed=1)
+            p1.spp_begin, p1.spp_end = 0, min(k, k1)
+            t0 = time.perf_counter()
+            _, cs1 = osc.render(hs.camera, p1, threads=1)
+            dt1 = time.perf_counter() - t0
             cpu = {"value": round(cpu_rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                    "sample": f"{scene_name} {sw}x{sh_}, samples 0..{k} of {spp} per pixel, {cpu_rays} rays in {dt:.1f} s "
-                             f"(C++ restatement of the reference with its median-split BVH; counts every ray the reference traces)"}
+                             f"(C++ restatement of the reference with its median-split BVH; counts every ray the reference traces)",
+                   "single_thread": {"value": round((cs1.rays_closest + cs1.rays_shadow) / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                     "sample": f"samples 0..{p1.spp_end} of the same frame, {cs1.rays_closest + cs1.rays_shadow} rays in {dt1:.1f} s"}}
+            # The GPU does not trace rays whose weight is exactly zero (the reference traces them and multiplies by zero):
+            # the same sample on the GPU gives the fraction of the reference's rays that `value` does not count.
+            scratch = torch.zeros((sh_, sw, 3), dtype=torch.float32, device=dev)
+            torch.cuda.current_stream().synchronize()
+            gst = ds.render_device(hs.camera, pp, scratch.data_ptr())
+            gpu_rays = gst.rays_closest + gst.rays_shadow
+            pruned = {"fraction": round(1.0 - gpu_rays / max(1, cpu_rays), 5), "gpu_rays": gpu_rays, "reference_rays": cpu_rays,
+                      "note": "rays of zero weight the GPU skips; value counts only rays actually traced"}
 
         result = {
             "metric": "Mrays/sec (whole node) + time-to-image, 1080p 256spp, 1/2/4/8 MI355X",
-            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {scene_name} {W}x{H} {spp} spp, {shader_name} shader", "shard": args.shard,
                        "rays_per_step": total_rays / steps, "camera_samples_per_step": total_cam / steps,
                        "time_to_image_ms": round(ms_per_step, 2), "scene_upload_ms": round(scene_ms, 2),
+                       "cold_time_to_image_ms": round(cold_ms, 1), "device_bytes": int(stats[-1].device_bytes) if stats else 0,
+                       "zero_weight_rays_pruned": pruned,
                        "stage_ms_per_step_rank0": {k: round(v, 2) for k, v in stage_ms.items()}},
             "roofline": roofline, "cpu_baseline": cpu,
         }

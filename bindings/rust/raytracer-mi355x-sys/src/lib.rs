@@ -33,7 +33,8 @@ pub const RT_ERR_NOMEM: i32 = 4;
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct rt_stats { pub camera_samples: u64, pub rays_closest: u64,
     pub rays_shadow: u64, pub nodes_visited: u64, pub tris_tested: u64, pub iterations: u64,
     pub launches_extend: u64, pub launches_shade: u64, pub launches_shadow: u64, pub launches_raygen: u64,
-    pub ms_total: f64, pub ms_extend: f64, pub ms_shade: f64, pub ms_shadow: f64, pub ms_raygen: f64 }
+    pub ms_total: f64, pub ms_extend: f64, pub ms_shade: f64, pub ms_shadow: f64, pub ms_raygen: f64,
+    pub device_bytes: u64 }
 pub enum rt_context {}
 pub enum rt_scene {}
 

@@ -139,6 +139,7 @@ typedef struct rt_stats {
     uint64_t launches_extend, launches_shade, launches_shadow, launches_raygen;
     double ms_total;         /* wall time of the call, device work complete */
     double ms_extend, ms_shade, ms_shadow, ms_raygen; /* RT_FLAG_TIMING: summed HIP-event durations */
+    uint64_t device_bytes;   /* device memory the context holds for queues and planes after this call */
 } rt_stats;
 
 typedef struct rt_context rt_context;

@@ -100,6 +100,17 @@ struct rt_scene {
     int n_point_lights = 0, n_disk_lights = 0;
 };
 
+// Device memory one render call works in: the two path-node queues, hit records, the two shadow-ray queues, the tiled
+// colour planes, the list of selected 8x8 blocks and the loop state.  rt_render points it at the context's pool (grown
+// on demand with hipMalloc).
+struct RenderPool {
+    float4 *qa[2], *qb[2], *qc[2], *sa[2], *sb[2];
+    float2 *hit, *sc2[2];
+    float *planes;
+    int32_t *blocks;
+    Ctl *ctl;
+};
+
 namespace {
 
 int set_device(rt_context *ctx) {
@@ -165,39 +176,51 @@ bool pixel_selected_host(const rt_params &p, int x, int y) {
     return t % p.shard_count == p.shard_rank;
 }
 
+// hipMalloc failures of the queue pool are reported as RT_ERR_NOMEM; any other HIP error as RT_ERR_DEVICE
+#define HIP_TRY_ALLOC(expr)                                                                                        \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ == hipErrorOutOfMemory) return fail(RT_ERR_NOMEM, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
 int ensure_queues(rt_context *ctx, uint32_t capacity, uint32_t shadow_capacity, size_t n_pixels) {
     if (capacity > ctx->capacity) {
+        // a failure part-way leaves some buffers freed: the pool counts as empty until every buffer has its new size
+        ctx->capacity = 0;
         for (int k = 0; k < 2; k++) {
-            HIP_TRY(ctx->qa[k].ensure(capacity));
-            HIP_TRY(ctx->qb[k].ensure(capacity));
-            HIP_TRY(ctx->qc[k].ensure(capacity));
+            HIP_TRY_ALLOC(ctx->qa[k].ensure(capacity));
+            HIP_TRY_ALLOC(ctx->qb[k].ensure(capacity));
+            HIP_TRY_ALLOC(ctx->qc[k].ensure(capacity));
         }
-        HIP_TRY(ctx->hit.ensure(capacity));
+        HIP_TRY_ALLOC(ctx->hit.ensure(capacity));
         ctx->capacity = capacity;
     }
     if (shadow_capacity > ctx->shadow_capacity) {
+        ctx->shadow_capacity = 0;
         for (int k = 0; k < 2; k++) {
-            HIP_TRY(ctx->sa[k].ensure(shadow_capacity));
-            HIP_TRY(ctx->sb[k].ensure(shadow_capacity));
-            HIP_TRY(ctx->sc2[k].ensure(shadow_capacity));
+            HIP_TRY_ALLOC(ctx->sa[k].ensure(shadow_capacity));
+            HIP_TRY_ALLOC(ctx->sb[k].ensure(shadow_capacity));
+            HIP_TRY_ALLOC(ctx->sc2[k].ensure(shadow_capacity));
         }
         ctx->shadow_capacity = shadow_capacity;
     }
-    HIP_TRY(ctx->planes.ensure(3 * n_pixels));
+    HIP_TRY_ALLOC(ctx->planes.ensure(3 * n_pixels));
     return RT_OK;
 }
 
 struct StageTimer {
     rt_context *ctx;
     bool on;
+    bool failed = false;
     size_t used = 0;
     struct Span { int stage; size_t e0; };
     std::vector<Span> spans;
     double ms[4] = {0, 0, 0, 0};
     hipEvent_t get() {
         if (used == ctx->events.size()) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; failed = true; return nullptr; } // timing is dropped, the render goes on
             ctx->events.push_back(e);
         }
         return ctx->events[used++];
@@ -206,16 +229,22 @@ struct StageTimer {
     void begin(int stage, hipStream_t stream = nullptr) {
         if (!on) return;
         cur_stream = stream ? stream : ctx->stream;
-        spans.push_back({stage, used});
-        (void)hipEventRecord(get(), cur_stream);
+        const size_t e0 = used;
+        hipEvent_t e = get();
+        if (!e) return;
+        spans.push_back({stage, e0});
+        (void)hipEventRecord(e, cur_stream);
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(get(), cur_stream);
+        hipEvent_t e = get();
+        if (!e) { spans.pop_back(); return; }
+        (void)hipEventRecord(e, cur_stream);
     }
     // call after a stream synchronisation
     void collect() {
-        if (!on) return;
+        if (!on && !failed) return;
+        if (failed) { spans.clear(); used = 0; for (double &m : ms) m = 0.0; return; }
         for (const Span &s : spans) {
             float t = 0.0f;
             if (hipEventElapsedTime(&t, ctx->events[s.e0], ctx->events[s.e0 + 1]) == hipSuccess) ms[s.stage] += t;
@@ -274,7 +303,7 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
     if (e != hipSuccess) {
-        delete ctx;
+        rt_context_destroy(ctx);
         return fail(RT_ERR_DEVICE, std::string("context creation: ") + hipGetErrorString(e));
     }
     *out = ctx;
@@ -413,6 +442,11 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
     const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 32);
     const bool ordered = env_u32_allow_zero("RT_BVH_ORDERED", 1) != 0;
     build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh);
+    // the traversal addresses nodes and triangles through 32-bit byte offsets of a buffer descriptor
+    if ((unsigned long long)bvh.n_nodes * (unsigned long long)bvh.n_orders * 32ull >= (1ull << 32) || (unsigned long long)d->n_tri * 48ull >= (1ull << 32)) {
+        rt_scene_destroy(s);
+        return fail(RT_ERR_INVALID, "scene too large: node or triangle array reaches 4 GiB");
+    }
     UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
     UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
     UP(s->sph, d->sph, d->n_sph, float4);
@@ -511,20 +545,17 @@ int32_t rt_scene_destroy(rt_scene *s) {
     return RT_OK;
 }
 
-int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *accum_rgb, int32_t accum_is_device, rt_stats *stats) {
-    if (!s || !cam || !p || !accum_rgb) return fail(RT_ERR_INVALID, "null argument");
-    int rc = check_params(*p);
-    if (rc) return rc;
-    rc = check_supported(*s, *p);
-    if (rc) return rc;
+// The render loop of rt_render.  `pool` = the device memory to work in (already large
+// enough for the given queue geometry), `accum_dev` = device sum buffer the planes are added into at the end.
+// Allocates no device memory unless RT_FLAG_TIMING asks for events.
+static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params *p, const RenderPool &pool, uint32_t seg_capacity,
+                              uint32_t shadow_seg_capacity, uint32_t target, float *accum_dev, rt_stats *stats_out,
+                              std::chrono::steady_clock::time_point t0) {
     rt_context *ctx = s->ctx;
-    rc = set_device(ctx);
-    if (rc) return rc;
-    auto t0 = std::chrono::steady_clock::now();
-
     const size_t n_pixels = (size_t)p->width * p->height;
     const RenderConst rcst = make_const(*cam, *p);
     const int n_samples = p->spp_end - p->spp_begin;
+    const size_t plane_stride = rcst.plane_stride; // the kernels index the colour planes by tile
 
     // 8x8 pixel blocks to render: all of them, or those touching this shard's tiles
     const uint32_t blocks_w = (uint32_t)((p->width + 7) / 8), blocks_h = (uint32_t)((p->height + 7) / 8);
@@ -543,51 +574,14 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
                 if (any) sel.push_back((int32_t)(by * blocks_w + bx));
             }
         n_blocks = (uint32_t)sel.size();
-        HIP_TRY(ctx->blocks.ensure(std::max<size_t>(1, sel.size())));
-        if (!sel.empty()) HIP_TRY(hipMemcpyAsync(ctx->blocks.p, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (!sel.empty()) HIP_TRY(hipMemcpyAsync(pool.blocks, sel.data(), sel.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream)); // sel goes out of scope
-        blocks_dev = ctx->blocks.p;
+        blocks_dev = pool.blocks;
     }
     const unsigned long long total = (unsigned long long)n_blocks * 64ull * (unsigned long long)std::max(0, n_samples);
 
-    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`.  The default keeps 64 Mi rays in
-    // flight (measured: 8 Mi -> 32 Mi is 3-8 % faster, 32 Mi -> 64 Mi another 2-3 %: fewer iterations, and the few long
-    // walks of a launch overlap with more short ones);
-    // that is about 100 GB of queues, so without an explicit RT_QUEUE_TARGET the level is halved until the queues fit
-    // into half of the free device memory.
-    const char *target_env = std::getenv("RT_QUEUE_TARGET");
-    const bool target_given = target_env && *target_env;
-    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 26);
-    // shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of
-    // LightList::visible for the Whitted shader (light.rs:368-385, 150-181)
-    uint32_t per_node = 1;
-    if (p->shader == RT_SHADER_WHITTED) per_node = (uint32_t)std::max(1, s->n_point_lights + s->n_disk_lights * std::max(1, p->light_samples));
-    if (per_node > 1) target = std::max<uint32_t>(1u << 16, target / 8);
-    if (total < target) target = (uint32_t)total;
-    uint32_t seg_capacity = 0, shadow_seg_capacity = 0;
-    for (;;) {
-        target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
-        // a segment holds 8x its even share of the refill level: bursts of branching (Microfacet spawns two rays per hit)
-        // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
-        seg_capacity = 8u * (target / RT_NSEG);
-        shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
-        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 8) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
-        const bool grows = (size_t)seg_capacity * RT_NSEG > ctx->capacity || (size_t)shadow_seg_capacity * RT_NSEG > ctx->shadow_capacity;
-        if (target_given || !grows || target <= (1u << 20)) break;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
-        if (const uint32_t pretend_mb = env_u32("RT_FREE_MEM_MB", 0)) free_b = (size_t)pretend_mb << 20; // for tests of this fallback
-        const size_t held = ctx->capacity * (size_t)(2 * 48 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
-        if (need <= (free_b + held) / 2) break;
-        target /= 2;
-    }
-    const size_t plane_stride = rcst.plane_stride; // the kernels index the colour planes by tile
-    rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, plane_stride);
-    if (rc) return rc;
-
     LaunchCfg cfg{ctx->stream, seg_capacity, shadow_seg_capacity, target};
-    HIP_TRY(hipMemsetAsync(ctx->planes.p, 0, 3 * plane_stride * sizeof(float), ctx->stream));
-
+    HIP_TRY(hipMemsetAsync(pool.planes, 0, 3 * plane_stride * sizeof(float), ctx->stream));
     rt_stats st;
     std::memset(&st, 0, sizeof(st));
     StageTimer timer{ctx, (p->flags & RT_FLAG_TIMING) != 0};
@@ -595,13 +589,13 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
 
     if (p->shader == RT_SHADER_NORMAL) {
         timer.begin(1);
-        launch_normal_shader(cfg, s->dev, rcst, ctx->planes.p, (uint32_t)n_pixels);
+        launch_normal_shader(cfg, s->dev, rcst, pool.planes, (uint32_t)n_pixels);
         timer.end();
         st.launches_shade = 1;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         timer.collect();
     } else if (total > 0) {
-        HIP_TRY(hipMemsetAsync(ctx->ctl, 0, sizeof(Ctl), ctx->stream));
+        HIP_TRY(hipMemsetAsync(pool.ctl, 0, sizeof(Ctl), ctx->stream));
         std::memset(ctx->ctl_host, 0, sizeof(CtlHead));
         ctx->ctl_host->total = total;
         ctx->ctl_host->per_sample = n_blocks * 64u;
@@ -610,7 +604,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         uint32_t chunk_samples = env_u32("RT_TILE_SAMPLES", 16);
         while (chunk_samples > 1 && (unsigned long long)n_blocks * 64ull * chunk_samples >= (1ull << 30)) chunk_samples /= 2;
         ctx->ctl_host->chunk_samples = chunk_samples;
-        HIP_TRY(hipMemcpyAsync(&ctx->ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&pool.ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int cur = 0, scur = 0;
         // The occlusion queries an iteration's shading queues are traced during the NEXT iteration, on a second stream
@@ -625,8 +619,8 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         for (;;) {
             if (shadow_pending && overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->shadow_done, 0)); // k_plan rewrites the counts k_shadow reads
             shadow_pending = false;
-            launch_plan(cfg, ctx->ctl);
-            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &ctx->ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
+            launch_plan(cfg, pool.ctl);
+            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &pool.ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
@@ -637,11 +631,11 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
                              c.max_sh_heavy);
             // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
             if (c.max_sh_light || c.max_sh_heavy) {
-                ShadowQueue filled{ctx->sa[scur ^ 1].p, ctx->sb[scur ^ 1].p, ctx->sc2[scur ^ 1].p};
+                ShadowQueue filled{pool.sa[scur ^ 1], pool.sb[scur ^ 1], pool.sc2[scur ^ 1]};
                 LaunchCfg scfg = cfg;
                 scfg.stream = shadow_stream;
                 timer.begin(2, shadow_stream);
-                launch_shadow(scfg, s->dev, rcst, ctx->ctl, filled, ctx->planes.p, (uint32_t)plane_stride, std::min(c.max_sh_light, shadow_seg_capacity),
+                launch_shadow(scfg, s->dev, rcst, pool.ctl, filled, pool.planes, (uint32_t)plane_stride, std::min(c.max_sh_light, shadow_seg_capacity),
                               std::min(c.max_sh_heavy, shadow_seg_capacity), count_work);
                 timer.end();
                 if (overlap) HIP_TRY(hipEventRecord(ctx->shadow_done, shadow_stream));
@@ -649,12 +643,12 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
                 st.launches_shadow++;
             }
             if (c.done) break;
-            NodeQueue in{ctx->qa[cur].p, ctx->qb[cur].p, ctx->qc[cur].p};
-            NodeQueue out{ctx->qa[cur ^ 1].p, ctx->qb[cur ^ 1].p, ctx->qc[cur ^ 1].p};
-            ShadowQueue sh{ctx->sa[scur].p, ctx->sb[scur].p, ctx->sc2[scur].p};
+            NodeQueue in{pool.qa[cur], pool.qb[cur], pool.qc[cur]};
+            NodeQueue out{pool.qa[cur ^ 1], pool.qb[cur ^ 1], pool.qc[cur ^ 1]};
+            ShadowQueue sh{pool.sa[scur], pool.sb[scur], pool.sc2[scur]};
             if (c.n_new) {
                 timer.begin(3);
-                launch_raygen(cfg, s->dev, rcst, ctx->ctl, in, blocks_dev, blocks_w, c.n_new);
+                launch_raygen(cfg, s->dev, rcst, pool.ctl, in, blocks_dev, blocks_w, c.n_new);
                 timer.end();
                 st.launches_raygen++;
             }
@@ -667,7 +661,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             if (tail_limit && c.n_new == 0 && c.cursor == c.total && c.n_alive <= tail_limit) {
                 // the last few paths: one launch follows each of them to its end (see k_tail)
                 timer.begin(0);
-                launch_tail(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->planes.p, (uint32_t)plane_stride, light_threads, heavy_threads);
+                launch_tail(cfg, p->shader, s->dev, rcst, pool.ctl, in, out, pool.planes, (uint32_t)plane_stride, light_threads, heavy_threads);
                 timer.end();
                 st.launches_extend++;
                 hipError_t le = hipGetLastError();
@@ -677,11 +671,11 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
                 continue;
             }
             timer.begin(0);
-            launch_extend(cfg, s->dev, rcst, ctx->ctl, in, ctx->hit.p, light_threads, heavy_threads, count_work);
+            launch_extend(cfg, s->dev, rcst, pool.ctl, in, pool.hit, light_threads, heavy_threads, count_work);
             timer.end();
             st.launches_extend++;
             timer.begin(1);
-            launch_shade(cfg, p->shader, s->dev, rcst, ctx->ctl, in, out, ctx->hit.p, sh, ctx->planes.p, (uint32_t)plane_stride, light_threads, heavy_threads);
+            launch_shade(cfg, p->shader, s->dev, rcst, pool.ctl, in, out, pool.hit, sh, pool.planes, (uint32_t)plane_stride, light_threads, heavy_threads);
             timer.end();
             st.launches_shade++;
             hipError_t le = hipGetLastError();
@@ -690,9 +684,12 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
             scur ^= 1;
         }
         if (overlap) HIP_TRY(hipStreamSynchronize(ctx->stream2));
+        // the last occlusion launch and the tail kernel add to the counters after the loop's last read-back
+        HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &pool.ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         timer.collect();
         const CtlHead c = *ctx->ctl_host;
+        if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
         st.camera_samples = c.cam_samples;
         st.rays_closest = c.rays_closest;
         st.rays_shadow = c.rays_shadow;
@@ -712,16 +709,8 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
 
     // add the planes into the caller's interleaved sum buffer
-    if (accum_is_device) {
-        launch_planes_to_rgb(cfg, rcst, ctx->planes.p, accum_rgb, (uint32_t)n_pixels);
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    } else {
-        HIP_TRY(ctx->accum_tmp.ensure(3 * n_pixels));
-        HIP_TRY(hipMemcpyAsync(ctx->accum_tmp.p, accum_rgb, 3 * n_pixels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        launch_planes_to_rgb(cfg, rcst, ctx->planes.p, ctx->accum_tmp.p, (uint32_t)n_pixels);
-        HIP_TRY(hipMemcpyAsync(accum_rgb, ctx->accum_tmp.p, 3 * n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
+    launch_planes_to_rgb(cfg, rcst, pool.planes, accum_dev, (uint32_t)n_pixels);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("render: ") + hipGetErrorString(le));
 
@@ -730,6 +719,85 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     if (p->shader == RT_SHADER_NORMAL) {
         st.camera_samples = 0; // not tracked by the single-kernel normal shader
     }
+    if (stats_out) *stats_out = st;
+    return RT_OK;
+}
+
+// shadow rays one shaded node can emit: 1 (next-event estimation), or every light sample of LightList::visible for the
+// Whitted shader (light.rs:368-385, 150-181)
+static uint32_t shadow_rays_per_node(const rt_scene *s, const rt_params *p) {
+    if (p->shader != RT_SHADER_WHITTED) return 1;
+    return (uint32_t)std::max(1, s->n_point_lights + s->n_disk_lights * std::max(1, p->light_samples));
+}
+
+int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *accum_rgb, int32_t accum_is_device, rt_stats *stats) {
+    if (!s || !cam || !p || !accum_rgb) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*p);
+    if (rc) return rc;
+    rc = check_supported(*s, *p);
+    if (rc) return rc;
+    rt_context *ctx = s->ctx;
+    rc = set_device(ctx);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+
+    const size_t n_pixels = (size_t)p->width * p->height;
+    const size_t plane_stride = 64u * (size_t)((p->width + 7) / 8) * (size_t)((p->height + 7) / 8);
+    const unsigned long long total = (unsigned long long)plane_stride * (unsigned long long)std::max(0, p->spp_end - p->spp_begin);
+
+    // queue geometry: RT_NSEG segments per queue, sized from the refill level `target`.  The default keeps 32 Mi rays in
+    // flight (measured: 8 Mi -> 32 Mi is 3-8 % faster: fewer iterations, and the few long walks of a launch overlap with
+    // more short ones; 64 Mi gives another 2-3 % but doubles the footprint to about 100 GB);
+    // that is about 50 GB of queues, so without an explicit RT_QUEUE_TARGET the level is halved until the queues fit
+    // into half of the free device memory.
+    const char *target_env = std::getenv("RT_QUEUE_TARGET");
+    const bool target_given = target_env && *target_env;
+    uint32_t target = env_u32("RT_QUEUE_TARGET", 1u << 25);
+    const uint32_t per_node = shadow_rays_per_node(s, p);
+    if (per_node > 1) target = std::max<uint32_t>(1u << 16, target / 8);
+    if (total < target) target = (uint32_t)total;
+    uint32_t seg_capacity = 0, shadow_seg_capacity = 0;
+    for (;;) {
+        target = std::max<uint32_t>((target + 255u) & ~255u, 1u << 14);
+        // a segment holds 8x its even share of the refill level: bursts of branching (Microfacet spawns two rays per hit)
+        // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
+        seg_capacity = 8u * (target / RT_NSEG);
+        shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
+        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 8) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
+        const bool grows = (size_t)seg_capacity * RT_NSEG > ctx->capacity || (size_t)shadow_seg_capacity * RT_NSEG > ctx->shadow_capacity;
+        if (target_given || !grows || target <= (1u << 20)) break;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+        if (const uint32_t pretend_mb = env_u32("RT_FREE_MEM_MB", 0)) free_b = (size_t)pretend_mb << 20; // for tests of this fallback
+        const size_t held = ctx->capacity * (size_t)(2 * 48 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
+        if (need <= (free_b + held) / 2) break;
+        target /= 2;
+    }
+    rc = ensure_queues(ctx, seg_capacity * RT_NSEG, shadow_seg_capacity * RT_NSEG, plane_stride);
+    if (rc) return rc;
+    if (p->tile_size > 0) HIP_TRY_ALLOC(ctx->blocks.ensure(std::max<size_t>(1, plane_stride / 64)));
+    float *accum_dev = accum_rgb;
+    if (!accum_is_device) {
+        HIP_TRY_ALLOC(ctx->accum_tmp.ensure(3 * n_pixels));
+        HIP_TRY(hipMemcpyAsync(ctx->accum_tmp.p, accum_rgb, 3 * n_pixels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        accum_dev = ctx->accum_tmp.p;
+    }
+    RenderPool pool;
+    for (int k = 0; k < 2; k++) {
+        pool.qa[k] = ctx->qa[k].p; pool.qb[k] = ctx->qb[k].p; pool.qc[k] = ctx->qc[k].p;
+        pool.sa[k] = ctx->sa[k].p; pool.sb[k] = ctx->sb[k].p; pool.sc2[k] = ctx->sc2[k].p;
+    }
+    pool.hit = ctx->hit.p; pool.planes = ctx->planes.p; pool.blocks = ctx->blocks.p; pool.ctl = ctx->ctl;
+    rt_stats st;
+    rc = render_in_pool(s, cam, p, pool, seg_capacity, shadow_seg_capacity, target, accum_dev, &st, t0);
+    if (rc) return rc;
+    if (!accum_is_device) {
+        HIP_TRY(hipMemcpyAsync(accum_rgb, ctx->accum_tmp.p, 3 * n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    st.device_bytes = (uint64_t)ctx->capacity * (2 * 48 + 8) + (uint64_t)ctx->shadow_capacity * (2 * 40) + (uint64_t)ctx->planes.n * sizeof(float) +
+                      (uint64_t)ctx->accum_tmp.n * sizeof(float) + (uint64_t)ctx->blocks.n * sizeof(int32_t) + sizeof(Ctl);
     if (stats) *stats = st;
     return RT_OK;
 }

@@ -516,6 +516,24 @@ __device__ __forceinline__ void shade_node(const DevScene &sc, const RenderConst
     }
 }
 
+// One shadow ray per lane for the Whitted shader's LightList::visible (light.rs:368-385), appended to the light or the
+// heavy segment `seg_l` of the shadow queue according to the ray's own class: the occlusion kernel scans only the
+// triangles outside the big meshes for the rays of a light segment.  One returning atomic per wave and class; every
+// lane of the wave must call it.
+__device__ __forceinline__ void append_shadow_classified(const DevScene &sc, const RenderConst &rc, Ctl *ctl, const ShadowQueue &sh, bool valid, F3 o,
+                                                         F3 d, F3 c, uint32_t pixel_index, uint32_t seg_l, uint32_t shadow_seg_capacity) {
+    const bool heavy = valid && ray_is_heavy(sc, o, d, rc.t_min, 1.0f - rc.t_min);
+    const uint32_t slot_l = wave_append(valid && !heavy, &ctl->seg_shadow[seg_l].v);
+    const uint32_t slot_h = wave_append(heavy, &ctl->seg_shadow[RT_NSEG_HALF + seg_l].v);
+    if (!valid) return;
+    const uint32_t slot = heavy ? slot_h : slot_l;
+    if (slot >= shadow_seg_capacity) { ctl->h.overflow = 1; return; }
+    const uint32_t i = ray_segment(heavy, seg_l) * shadow_seg_capacity + slot;
+    sh.a[i] = make_float4(o.x, o.y, o.z, d.x);
+    sh.b[i] = make_float4(d.y, d.z, c.x, c.y);
+    sh.c[i] = make_float2(c.z, __uint_as_float(pixel_index));
+}
+
 // ---- k_shade ---------------------------------------------------------------------------------------------------------
 // grid (blocks, RT_NSEG) like k_extend.  Children go to segment (bx + s) % RT_NSEG of the next queue, which spreads
 // every segment's offspring over all segments and keeps them level.
@@ -558,8 +576,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     if (have1) {
         if (slot[1] < seg_capacity) store_node(out, seg3[1] * seg_capacity + slot[1], c1); else ctl->h.overflow = 1;
     }
-    const uint32_t oseg = oseg_l; // the Whitted multi-ray path below does not classify
-
     if (SHADER == RT_SHADER_WHITTED) {
         // LightList::visible (light.rs:368-385): every light; a disk light is sampled light_samples times (light.rs:150-181)
         for (int l = 0; l < sc.n_light; l++) {
@@ -569,16 +585,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                 F3 dir = f3(L.ox, L.oy, L.oz) - vis_p;
                 F3 c = f3(0.0f, 0.0f, 0.0f);
                 if (vis_pending) c = mul_v(vis_w, spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)); // light.rs:79
-                bool v = vis_pending && !is_black(c);
-                uint32_t slot = wave_append(v, &ctl->seg_shadow[oseg].v);
-                if (v) {
-                    if (slot < shadow_seg_capacity) {
-                        slot += oseg * shadow_seg_capacity;
-                        sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
-                        sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
-                        sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
-                    } else ctl->h.overflow = 1;
-                }
+                const bool v = vis_pending && !is_black(c);
+                append_shadow_classified(sc, rc, ctl, sh, v, vis_p, dir, c, s_pixel, oseg_l, shadow_seg_capacity);
             } else if (L.kind == RT_LIGHT_DISK) {
                 const float range = L.radius * 2.0f;
                 const bool white = L.sampler_kind == RT_SAMPLER_WHITE || L.sampler_kind == RT_SAMPLER_BLUE;
@@ -621,16 +629,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
                     F3 dir = origin - vis_p;
                     F3 c = f3(0.0f, 0.0f, 0.0f);
                     if (have) c = mul_v(vis_w, (spectrum * dot(normalize(dir), normalize(vis_n)) / dot(dir, dir)) * scale); // light.rs:171,175-177
-                    bool v = have && !is_black(c);
-                    uint32_t slot = wave_append(v, &ctl->seg_shadow[oseg].v);
-                    if (v) {
-                        if (slot < shadow_seg_capacity) {
-                            slot += oseg * shadow_seg_capacity;
-                            sh.a[slot] = make_float4(vis_p.x, vis_p.y, vis_p.z, dir.x);
-                            sh.b[slot] = make_float4(dir.y, dir.z, c.x, c.y);
-                            sh.c[slot] = make_float2(c.z, __uint_as_float(s_pixel));
-                        } else ctl->h.overflow = 1;
-                    }
+                    const bool v = have && !is_black(c);
+                    append_shadow_classified(sc, rc, ctl, sh, v, vis_p, dir, c, s_pixel, oseg_l, shadow_seg_capacity);
                 }
             }
         }

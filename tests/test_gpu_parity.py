@@ -311,6 +311,40 @@ def test_axis_aligned_cube_is_intact(rt, orc, gpu_ctx):
     ds.close()
 
 
+@pytest.mark.parametrize("light_kind", ["point", "disk"])
+def test_whitted_shadow_of_a_big_mesh_on_a_small_floor(rt, orc, gpu_ctx, light_kind):
+    """A mesh of >= 64 faces (its rays walk the BVH) above a two-triangle floor (rays that miss the mesh's box only scan
+    the floor): the Whitted shader's shadow rays (src/light.rs:60-81,150-181) towards the light pass through the mesh
+    and must be occluded by it, so each of them is classified on its own before it is queued."""
+    teapot = rt.load_obj(os.path.join(rt.ASSET_DIR, "utah.obj"))
+    mesh = rt.transform_points(teapot.reshape(-1, 3), 0.12, (0.0, -0.5, -2.0), 0, 0, 0).reshape(-1, 9)
+    floor = np.array([[-2, -1, 0, 2, -1, 0, 2, -1, -4], [-2, -1, 0, 2, -1, -4, -2, -1, -4]], np.float32)
+    tri_v = np.concatenate([floor, mesh.astype(np.float32)])
+    n_mesh = len(mesh)
+    if light_kind == "point":
+        light = rt.Light(rt.LIGHT_POINT, (0.2, 1.5, -2.0), 0, (9, 9, 9), 0, 0, 1)
+    else:
+        light = rt.Light(rt.LIGHT_DISK, (0.2, 1.5, -2.0), 0.4, (9, 9, 9), 0, 0, rt.SAMPLER_UNIFORM)
+    sc = rt.NumpyScene(tri_v=tri_v, tri_mat=[0] * len(tri_v), mats=[rt.diffuse(0.8, 0.8, 0.8)],
+                       objects=[rt.Object(rt.OBJ_TRIANGLE, 0, 1, 0), rt.Object(rt.OBJ_TRIANGLE, 1, 1, 0), rt.Object(rt.OBJ_MESH, 2, n_mesh, 2)],
+                       lights=[light])
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    osc = orc.OracleScene(sc.desc, 0, sc)
+    cam = rt.camera_new((0, 0.3, 2), (0, -0.5, -2), (0, 1, 0), 90.0, 1.0)
+    p = rt.default_params(64, 64, 2, shader=rt.SHADER_WHITTED)
+    gp, gt = ds.primary_hits(cam, p)
+    cp, ct = osc.primary_hits(cam, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    ga, gs = ds.render(cam, p)
+    ca, cs = osc.render(cam, p)
+    # the floor holds both lit and shadowed pixels: the mesh casts a shadow
+    on_floor = (cp.reshape(-1) >= 0) & (cp.reshape(-1) < 2)
+    lum = ca.reshape(-1, 3)[on_floor].sum(axis=1)
+    assert (lum == 0).any() and (lum > 0).any()
+    assert_radiance_close(ga, ca)
+    ds.close()
+
+
 # ---- error behaviour ----------------------------------------------------------------------------------------------
 def test_unsupported_shader_combinations(rt, gpu_ctx):
     hs = rt.HostScene("head", 1.0)

@@ -5,8 +5,20 @@ streams, so it is doubled.  Usage: pmc_summary.py <fetch.csv> <write.csv> <workl
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+
+def source_id():
+    """Same hash as bench.py's source_id(): the sources the device library is built from."""
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer-rs_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def load(path, counter):
@@ -24,7 +36,7 @@ def load(path, counter):
 
 fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, nw = load(sys.argv[2], "WRITE_SIZE")
-out = {"workload": sys.argv[3], "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB * 1024; FETCH_SIZE doubled (gfx950)",
+out = {"workload": sys.argv[3], "source_id": source_id(), "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB * 1024; FETCH_SIZE doubled (gfx950)",
        "bytes_per_launch": {}, "detail": {}}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):

@@ -46,6 +46,8 @@ extern "C" {
     pub fn rt_scene_destroy(scene: *mut rt_scene) -> i32;
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_params, accum_rgb: *mut f32,
                      accum_is_device: i32, stats: *mut rt_stats) -> i32;
+    pub fn rt_render_static(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_params, accum_rgb_dev: *mut f32,
+                            stats: *mut rt_stats) -> i32;   // no counterpart in the reference: for callers that cannot allocate
     pub fn rt_primary_hits(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_params,
                            prim_id: *mut i32, t: *mut f32) -> i32;
     pub fn rt_resolve(accum_rgb: *const f32, n_pixels: i64, spp: i32, out_i32: *mut i32, rgb8: *mut u8) -> i32;

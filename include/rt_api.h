@@ -166,6 +166,20 @@ int32_t rt_scene_destroy(rt_scene *scene);
 int32_t rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params, float *accum_rgb,
                   int32_t accum_is_device, rt_stats *stats);
 
+/*
+ * No counterpart in the reference.  rt_render for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and results as rt_render with
+ * accum_is_device != 0 (accum_rgb_dev must be a device pointer), but the path queues, hit records, shadow queues,
+ * colour planes and loop counters live in a fixed array in device memory (about 122 MB per GPU, held from library
+ * load until the process ends) instead of the context's pool, and the call creates no events: it calls no hipMalloc,
+ * hipFree or other allocating routine.  Limits, rejected with RT_ERR_INVALID: ceil(width/8)*ceil(height/8)*64 <= 2^21
+ * pixels (1920x1080 fits), RT_FLAG_TIMING not set, and for the Whitted shader at most 64 shadow rays per surface
+ * point.  The refill level is fixed at 2^16 path nodes, so large frames take more iterations than with rt_render.
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two threads, two contexts, two
+ * processes do NOT share it; two contexts of one process do) race.
+ */
+int32_t rt_render_static(rt_scene *scene, const rt_camera *cam, const rt_params *params, float *accum_rgb_dev, rt_stats *stats);
+
 /* Parity AOV: primitive id (-1 = miss) and t of world.objects.hit(primary ray, t_min, t_max) for the sample
  * spp_begin of every pixel (src/shader.rs:99 with depth 0).  Host output buffers of width*height entries. */
 int32_t rt_primary_hits(rt_scene *scene, const rt_camera *cam, const rt_params *params, int32_t *prim_id, float *t);

@@ -298,6 +298,8 @@ def hip_lib() -> C.CDLL:
         lib.rt_scene_destroy.restype = C.c_int32
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_int32, C.POINTER(Stats)]
         lib.rt_render.restype = C.c_int32
+        lib.rt_render_static.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        lib.rt_render_static.restype = C.c_int32
         lib.rt_primary_hits.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), c_int32_p, c_float_p]
         lib.rt_primary_hits.restype = C.c_int32
         lib.rt_resolve.argtypes = [c_float_p, C.c_int64, C.c_int32, c_int32_p, C.POINTER(C.c_uint8)]
@@ -387,6 +389,12 @@ class DeviceScene:
         """Same, into a device buffer of width*height*3 floats given by address (e.g. torch.Tensor.data_ptr())."""
         st = Stats()
         _check(hip_lib().rt_render(self._h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr), 1, C.byref(st)))
+        return st
+
+    def render_static(self, cam: Camera, params: Params, accum_ptr: int) -> Stats:
+        """rt_render_static: as render_device, but in the library's fixed device array (no allocation on the call)."""
+        st = Stats()
+        _check(hip_lib().rt_render_static(self._h, C.byref(cam), C.byref(params), C.c_void_p(accum_ptr), C.byref(st)))
         return st
 
     def primary_hits(self, cam: Camera, params: Params) -> Tuple[np.ndarray, np.ndarray]:

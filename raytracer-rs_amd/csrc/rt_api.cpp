@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,7 @@ struct rt_context {
     DevBuf<int32_t> blocks, prim_tmp;
     DevBuf<float> t_tmp;
     Ctl *ctl = nullptr;          // device
+    unsigned char *scratch_ptr = nullptr; // this device's copy of the fixed array behind rt_render_static
     CtlHead *ctl_host = nullptr; // pinned copy of the head
     std::vector<hipEvent_t> events;
 };
@@ -102,7 +104,7 @@ struct rt_scene {
 
 // Device memory one render call works in: the two path-node queues, hit records, the two shadow-ray queues, the tiled
 // colour planes, the list of selected 8x8 blocks and the loop state.  rt_render points it at the context's pool (grown
-// on demand with hipMalloc).
+// on demand with hipMalloc); rt_render_static points it at a fixed array that exists from library load on.
 struct RenderPool {
     float4 *qa[2], *qb[2], *qc[2], *sa[2], *sb[2];
     float2 *hit, *sc2[2];
@@ -110,6 +112,31 @@ struct RenderPool {
     int32_t *blocks;
     Ctl *ctl;
 };
+
+// ---- the fixed array behind rt_render_static ----------------------------------------------------------------------
+// Refill level 2^16 path nodes: segments of 16384 nodes / shadow rays (8x their even share), frames of at most 2^21
+// pixels after padding to 8x8 blocks (1920x1080 fits).
+#define RT_STATIC_TARGET (1u << 16)
+#define RT_STATIC_SEG_CAPACITY (8u * (RT_STATIC_TARGET / RT_NSEG))
+#define RT_STATIC_CAPACITY ((size_t)RT_STATIC_SEG_CAPACITY * RT_NSEG)
+#define RT_STATIC_MAX_PIXELS ((size_t)1 << 21)
+#define RT_STATIC_ALIGN(x) (((size_t)(x) + 255u) & ~(size_t)255u)
+#define RT_STATIC_OFF_CTL ((size_t)0)
+#define RT_STATIC_OFF_BLOCKS (RT_STATIC_OFF_CTL + RT_STATIC_ALIGN(sizeof(Ctl)))
+#define RT_STATIC_OFF_PLANES (RT_STATIC_OFF_BLOCKS + RT_STATIC_ALIGN((RT_STATIC_MAX_PIXELS / 64) * sizeof(int32_t)))
+#define RT_STATIC_OFF_NODES (RT_STATIC_OFF_PLANES + RT_STATIC_ALIGN(3 * RT_STATIC_MAX_PIXELS * sizeof(float)))
+#define RT_STATIC_OFF_HIT (RT_STATIC_OFF_NODES + 6 * RT_STATIC_CAPACITY * sizeof(float4))
+#define RT_STATIC_OFF_SHADOW (RT_STATIC_OFF_HIT + RT_STATIC_CAPACITY * sizeof(float2))
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_OFF_SHADOW + RT_STATIC_CAPACITY * (4 * sizeof(float4) + 2 * sizeof(float2)))
+
+// In host code this name is only a handle for hipGetSymbolAddress: every GPU holds its own copy at its own address,
+// looked up once per device in rt_context_create and kept in g_scratch_ptr.  Host code never passes the name itself
+// to a kernel, a memset or a copy.
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+#define RT_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[RT_MAX_DEVICES]; // per device; written under g_scratch_mutex
+static std::mutex g_scratch_mutex;
 
 namespace {
 
@@ -302,6 +329,16 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->shadow_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
+    if (e == hipSuccess && device_id < RT_MAX_DEVICES) {
+        // address of this device's copy of the fixed array (the device is current: hipSetDevice above)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_id]) {
+            void *ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_ptr[device_id] = static_cast<unsigned char *>(ptr);
+        }
+        ctx->scratch_ptr = g_scratch_ptr[device_id];
+    }
     if (e != hipSuccess) {
         rt_context_destroy(ctx);
         return fail(RT_ERR_DEVICE, std::string("context creation: ") + hipGetErrorString(e));
@@ -545,7 +582,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     return RT_OK;
 }
 
-// The render loop of rt_render.  `pool` = the device memory to work in (already large
+// The render loop shared by rt_render and rt_render_static.  `pool` = the device memory to work in (already large
 // enough for the given queue geometry), `accum_dev` = device sum buffer the planes are added into at the end.
 // Allocates no device memory unless RT_FLAG_TIMING asks for events.
 static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params *p, const RenderPool &pool, uint32_t seg_capacity,
@@ -798,6 +835,57 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     st.device_bytes = (uint64_t)ctx->capacity * (2 * 48 + 8) + (uint64_t)ctx->shadow_capacity * (2 * 40) + (uint64_t)ctx->planes.n * sizeof(float) +
                       (uint64_t)ctx->accum_tmp.n * sizeof(float) + (uint64_t)ctx->blocks.n * sizeof(int32_t) + sizeof(Ctl);
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+// rt_render for callers that cannot allocate: device sum buffer only, everything else lives in this device's copy of
+// the fixed array (ctx->scratch_ptr).  No hipMalloc / hipFree / event creation on this path.  The array is shared by
+// every call on the GPU and keeps the last call's contents: the loop state and the planes are cleared at the start
+// of every call (render_in_pool), queue slots are written before they are read.  Calls that overlap on one GPU race.
+int32_t rt_render_static(rt_scene *s, const rt_camera *cam, const rt_params *p, float *accum_rgb_dev, rt_stats *stats) {
+    if (!s || !cam || !p || !accum_rgb_dev) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(*p);
+    if (rc) return rc;
+    rc = check_supported(*s, *p);
+    if (rc) return rc;
+    rt_context *ctx = s->ctx;
+    if (!ctx->scratch_ptr) return fail(RT_ERR_DEVICE, "rt_render_static: the fixed array was not found on this device");
+    if (p->flags & RT_FLAG_TIMING) return fail(RT_ERR_INVALID, "rt_render_static: RT_FLAG_TIMING creates events; not available on the no-allocation path");
+    const size_t plane_stride = 64u * (size_t)((p->width + 7) / 8) * (size_t)((p->height + 7) / 8);
+    if (plane_stride > RT_STATIC_MAX_PIXELS)
+        return fail(RT_ERR_INVALID, "rt_render_static: frame too large: at most 2^21 pixels after padding width and height to multiples of 8 (use rt_render)");
+    // the refill level the fixed segments can take: a shaded node of the Whitted shader emits per_node shadow rays
+    const uint32_t per_node = shadow_rays_per_node(s, p);
+    uint32_t target = RT_STATIC_TARGET;
+    if (per_node > 1) target = std::min<uint32_t>(target, ((RT_STATIC_SEG_CAPACITY / (4u * per_node)) * RT_NSEG) & ~255u);
+    if (target < 2048u) return fail(RT_ERR_INVALID, "rt_render_static: too many shadow rays per surface point for the fixed queues (use rt_render)");
+    rc = set_device(ctx);
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned char *base = ctx->scratch_ptr;
+    RenderPool pool;
+    pool.ctl = reinterpret_cast<Ctl *>(base + RT_STATIC_OFF_CTL);
+    pool.blocks = reinterpret_cast<int32_t *>(base + RT_STATIC_OFF_BLOCKS);
+    pool.planes = reinterpret_cast<float *>(base + RT_STATIC_OFF_PLANES);
+    float4 *nodes = reinterpret_cast<float4 *>(base + RT_STATIC_OFF_NODES);
+    for (int k = 0; k < 2; k++) {
+        pool.qa[k] = nodes + (size_t)(3 * k + 0) * RT_STATIC_CAPACITY;
+        pool.qb[k] = nodes + (size_t)(3 * k + 1) * RT_STATIC_CAPACITY;
+        pool.qc[k] = nodes + (size_t)(3 * k + 2) * RT_STATIC_CAPACITY;
+    }
+    pool.hit = reinterpret_cast<float2 *>(base + RT_STATIC_OFF_HIT);
+    float4 *sh4 = reinterpret_cast<float4 *>(base + RT_STATIC_OFF_SHADOW);
+    float2 *sh2 = reinterpret_cast<float2 *>(sh4 + 4 * RT_STATIC_CAPACITY);
+    for (int k = 0; k < 2; k++) {
+        pool.sa[k] = sh4 + (size_t)(2 * k + 0) * RT_STATIC_CAPACITY;
+        pool.sb[k] = sh4 + (size_t)(2 * k + 1) * RT_STATIC_CAPACITY;
+        pool.sc2[k] = sh2 + (size_t)k * RT_STATIC_CAPACITY;
+    }
+    rt_stats st;
+    rc = render_in_pool(s, cam, p, pool, RT_STATIC_SEG_CAPACITY, RT_STATIC_SEG_CAPACITY, target, accum_rgb_dev, &st, t0);
+    if (rc) return rc;
+    st.device_bytes = RT_STATIC_SCRATCH_BYTES;
     if (stats) *stats = st;
     return RT_OK;
 }

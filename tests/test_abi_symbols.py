@@ -26,7 +26,7 @@ def test_exports(header, lib):
 def test_expected_entry_points_are_declared():
     api = declared_functions("rt_api.h")
     for n in ("rt_last_error", "rt_context_create", "rt_context_destroy", "rt_scene_create", "rt_scene_destroy", "rt_render",
-              "rt_primary_hits", "rt_resolve", "rt_resolve_device", "rt_context_stream", "rt_params_default", "rt_bvh_build_host"):
+              "rt_render_static", "rt_primary_hits", "rt_resolve", "rt_resolve_device", "rt_context_stream", "rt_params_default", "rt_bvh_build_host"):
         assert n in api
 
 

@@ -93,6 +93,7 @@ struct rt_scene {
     rt_context *ctx = nullptr;
     DevBuf<float4> nodes, tris, sph, loose;
     DevBuf<int2> sph_info, cyl_info;
+    DevBuf<int32_t> tri_of_prim;
     DevBuf<float> cyl, ltris;
     DevBuf<rt_material> mats;
     DevBuf<DevLight> lights;
@@ -565,6 +566,16 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *d, rt_scene **out)
         }
         UP(s->loose, loose.data(), loose.size() / 4, float4);
         s->dev.loose = s->loose.p;
+        // primitive id -> triangle record, for the walk that merges hits by (t, primitive id)
+        std::vector<int32_t> tri_of_prim((size_t)std::max(prim, 1), -1);
+        for (int i = 0; i < d->n_tri; i++) {
+            int32_t pid;
+            std::memcpy(&pid, &bvh.tris[12 * (size_t)i + 3], sizeof(pid));
+            tri_of_prim[(size_t)pid] = i;
+        }
+        UP(s->tri_of_prim, tri_of_prim.data(), tri_of_prim.size(), int32_t);
+        s->dev.tri_of_prim = s->tri_of_prim.p;
+        s->dev.deferred = env_u32_allow_zero("RT_DEFERRED", 1) != 0 ? 1 : 0;
     }
 #undef UP
     for (const DevLight &L : lights) { s->n_disk_lights += L.kind == RT_LIGHT_DISK; s->n_point_lights += L.kind == RT_LIGHT_POINT; }
@@ -577,7 +588,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     s->nodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
-    s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release();
+    s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
     delete s;
     return RT_OK;
 }

@@ -137,6 +137,9 @@ struct DevScene {
     // loop the whole wave runs together (the reference's own scan of the world list, hitable.rs:44-50) instead of walking the BVH.
     const float4 *loose;
     int32_t n_loose;
+    // heavy rays: exact triangle tests are queued per wave and run 64 at a time (bvh_traverse_deferred) when set
+    int32_t deferred;
+    const int32_t *tri_of_prim; // primitive id -> index into tris (-1 for spheres and cylinders)
     float heavy_min[4][3];
     float heavy_max[4][3];
 };
@@ -291,6 +294,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (link, miss) pairs are kept per order: [n_top x float4 (xmin,xmax,ymin,ymax)][n_top x float2 (zmin,zmax)]
 // [n_orders x n_top x int2 (link, miss)] = 24 + 8 * n_orders bytes per node.
 __host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (24u + 8u * (uint32_t)sc.n_orders); }
+// ... followed, 16-byte aligned, by one WaveWalkLds per wave of the workgroup
+__host__ __device__ __forceinline__ uint32_t wave_area_offset(const DevScene &sc, bool use_lds) { return use_lds ? ((top_cache_bytes(sc) + 15u) & ~15u) : 0u; }
 // every thread of the workgroup must call it
 template <int BLOCK_THREADS>
 __device__ __forceinline__ void fill_top_cache(const DevScene &sc, float4 *lds_nodes) {
@@ -398,6 +403,151 @@ __device__ __forceinline__ TriHit bvh_traverse(const DevScene &sc, const float4 
     return best;
 }
 
+// ---- wave-cooperative walk with deferred triangle tests ---------------------------------------------------------------
+// In the walk above a wave runs the exact triangle test (about 50 vector instructions with its IEEE division) every time
+// ANY of its lanes enters a leaf, for the two or three lanes that stand at one: on a mesh-dominated frame three quarters
+// of a wave's instructions are such iterations at 5 % lane utilisation.  Here a lane that enters a leaf only appends
+// (leaf, lane) to a queue of its wave in LDS and walks on; when 64 entries have gathered (or no lane has a node left)
+// the 64 lanes take one entry each and test its triangles for the ray of the entry's owner, read from LDS, so the test
+// runs with every lane busy.  A hit is merged into the owner's best with one 64-bit LDS minimum on the key
+// (t, 0x7FFFFFFF - primitive id): smaller t wins, equal t -> the larger primitive id (hitable.rs:44-50 + geometry.rs:53).
+// The owner culls with the best t it read last, which may be stale by a few steps: it then visits boxes it could have
+// skipped, never fewer, so the result is the same closest hit.  No workgroup barrier is involved: a wave only talks
+// to itself, and LDS operations of one wave complete in order.
+struct WaveWalkLds {
+    float4 ray_a[64];             // o.xyz, d.x
+    float2 ray_b[64];             // d.y, d.z
+    unsigned long long best[64];  // closest hit: key of the best hit so far; occlusion query: 0 once a hit is known
+    uint2 q[128];                 // ring of (packed leaf, owner lane)
+};
+
+__device__ __forceinline__ uint32_t float_order_key(float t) { // monotonic float -> uint
+    const uint32_t b = __float_as_uint(t);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Every lane of the wave must call it (valid = false for lanes without a ray); `wl` is the calling wave's own area.
+// Returns prim = primitive id of the closest hit (-1 = none) and tri = -1; the caller maps prim to the triangle record.
+template <bool ANY_HIT, bool COUNT, bool USE_LDS>
+__device__ __forceinline__ TriHit bvh_traverse_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
+                                                        float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
+    TriHit best{t_max, -1, -1};
+    if (sc.n_nodes == 0) return best;
+    const uint32_t lane = threadIdx.x & 63u;
+    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 32u);
+    const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
+    const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
+    const f32x2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
+    const f32x2 ox2 = {-o.x * ix, -o.x * ix}, oy2 = {-o.y * iy, -o.y * iy}, oz2 = {-o.z * iz, -o.z * iz};
+    const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
+    const uint32_t g_base = octant * (uint32_t)sc.n_nodes * 32u;
+    const float2 *l_box_b = reinterpret_cast<const float2 *>(lds_nodes + sc.n_top);
+    const float2 *l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
+
+    const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
+    wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+    wl.ray_b[lane] = make_float2(d.y, d.z);
+    wl.best[lane] = key0;
+    wave_lds_fence();
+
+    float cull_t = t_max; // the owner's view of its best t
+    int node = valid ? 0 : -1;
+    uint32_t head = 0, count = 0; // wave-uniform
+    for (;;) {
+        const bool walking = __ballot(node >= 0) != 0ull;
+        if (!walking && count == 0u) break;
+        if (walking && count < 64u) {
+            // one step of the walk for every lane that has a node; leaves are queued, not tested
+            int leaf = -1;
+            if (node >= 0) {
+                u32x4 na, nb;
+                if (USE_LDS && node < sc.n_top) {
+                    const float4 fa = lds_nodes[node];
+                    const float2 fb = l_box_b[node], fl = l_links[node];
+                    na = u32x4{__float_as_uint(fa.x), __float_as_uint(fa.y), __float_as_uint(fa.z), __float_as_uint(fa.w)};
+                    nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fl.x), __float_as_uint(fl.y)};
+                } else {
+                    na = load16(node_r, g_base + (uint32_t)node * 32u);
+                    nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);
+                }
+                if (COUNT) (*n_nodes)++;
+                const f32x2 tx = __builtin_elementwise_fma(f32x2{u2f(na.x), u2f(na.y)}, ix2, ox2);
+                const f32x2 ty = __builtin_elementwise_fma(f32x2{u2f(na.z), u2f(na.w)}, iy2, oy2);
+                const f32x2 tz = __builtin_elementwise_fma(f32x2{u2f(nb.x), u2f(nb.y)}, iz2, oz2);
+                const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
+                const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
+                const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
+                const int link = (int)nb.z, miss = (int)nb.w;
+                leaf = (inside && link < 0) ? ~link : -1;
+                node = (inside && link >= 0) ? link : miss;
+            }
+            const unsigned long long m = __ballot(leaf >= 0);
+            if (m != 0ull) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (leaf >= 0) wl.q[(head + count + rank) & 127u] = make_uint2((uint32_t)leaf, lane);
+                count += (uint32_t)__popcll(m);
+            }
+            continue;
+        }
+        // the exact tests of up to 64 queued leaves, one per lane
+        wave_lds_fence();
+        const uint32_t n = min(count, 64u);
+        if (lane < n) {
+            const uint2 e = wl.q[(head + lane) & 127u];
+            const uint32_t owner = e.y;
+            const unsigned long long seen = wl.best[owner];
+            if (!ANY_HIT || seen != 0ull) {
+                const float4 ra = wl.ray_a[owner];
+                const float2 rb = wl.ray_b[owner];
+                const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
+                float bound = ANY_HIT ? t_max : float_from_order_key((uint32_t)(seen >> 32));
+                const int first = (int)(e.x >> 3), cnt = (int)(e.x & 7u) + 1;
+                for (int k = 0; k < cnt; k++) {
+                    const uint32_t off = (uint32_t)(first + k) * 48u;
+                    const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
+                    if (COUNT) (*n_tris)++;
+                    float t;
+                    if (tri_hit(f3(u2f(a.x), u2f(a.y), u2f(a.z)), f3(u2f(b.x), u2f(b.y), u2f(b.z)), f3(u2f(c.x), u2f(c.y), u2f(c.z)), ro, rd, t_min, t_max, false, &t)) {
+                        if (ANY_HIT) {
+                            wl.best[owner] = 0ull;
+                            break;
+                        }
+                        if (t <= bound) { // never true for a NaN t
+                            bound = t;
+                            const unsigned long long key = ((unsigned long long)float_order_key(t) << 32) | (unsigned long long)(uint32_t)(0x7FFFFFFF - (int)a.w);
+                            atomicMin(&wl.best[owner], key);
+                        }
+                    }
+                }
+            }
+        }
+        head += n;
+        count -= n;
+        wave_lds_fence();
+        const unsigned long long mine = wl.best[lane];
+        if (ANY_HIT) {
+            if (mine == 0ull) node = -1;
+        } else {
+            cull_t = float_from_order_key((uint32_t)(mine >> 32));
+        }
+    }
+    const unsigned long long fin = wl.best[lane];
+    if (ANY_HIT) {
+        if (fin == 0ull) { best.tri = 0; best.prim = 0; }
+    } else if (fin != key0) {
+        best.t = float_from_order_key((uint32_t)(fin >> 32));
+        best.prim = 0x7FFFFFFF - (int)(uint32_t)fin;
+    }
+    return best;
+}
+
 // The loose triangles, one after the other, for a ray that misses the boxes of all big meshes.  The loop is the same for
 // every lane of the wave (no divergent walk) and the triangle data is uniform, so the loads are scalar.
 template <bool ANY_HIT, bool COUNT>
@@ -440,6 +590,48 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
     *t_out = closest;
     *code_out = code;
     *prim_out = prim;
+}
+
+// the same with the wave-cooperative walk: every lane of the wave must call it
+template <bool COUNT, bool USE_LDS>
+__device__ __forceinline__ void world_hit_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
+                                                   float t_max, float *t_out, int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
+    const TriHit th = bvh_traverse_deferred<false, COUNT, USE_LDS>(sc, lds_nodes, wl, valid, o, d, t_min, t_max, n_nodes, n_tris);
+    float closest = th.t;
+    int code = HIT_NONE, prim = th.prim;
+    if (!valid) return;
+    if (th.prim >= 0) code = hit_code(HIT_KIND_TRI, sc.tri_of_prim[th.prim]);
+    for (int i = 0; i < sc.n_sph; i++) {
+        float t;
+        if (sph_hit(sc.sph[i], o, d, t_min, closest, &t)) { closest = t; code = hit_code(HIT_KIND_SPH, i); prim = sc.sph_info[i].y; }
+    }
+    for (int i = 0; i < sc.n_cyl; i++) {
+        float t;
+        int kind;
+        if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, closest, &t, &kind)) { closest = t; code = hit_code(kind, i); prim = sc.cyl_info[i].y; }
+    }
+    *t_out = closest;
+    *code_out = code;
+    *prim_out = prim;
+}
+
+template <bool COUNT, bool USE_LDS>
+__device__ __forceinline__ bool world_occluded_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
+                                                        float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
+    bool occ = false;
+    if (valid) {
+        for (int i = 0; i < sc.n_sph && !occ; i++) {
+            float t;
+            occ = sph_hit(sc.sph[i], o, d, t_min, t_max, &t);
+        }
+        for (int i = 0; i < sc.n_cyl && !occ; i++) {
+            float t;
+            int kind;
+            occ = cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind);
+        }
+    }
+    const TriHit th = bvh_traverse_deferred<true, COUNT, USE_LDS>(sc, lds_nodes, wl, valid && !occ, o, d, t_min, t_max, n_nodes, n_tris);
+    return occ || th.tri >= 0;
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)

@@ -293,13 +293,18 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     if (bx * BLOCK >= n_seg) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0; // light rays scan the few triangles outside the big meshes
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
-    if (il >= n_seg) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
-    float t_obj;
-    int code, prim;
+    float t_obj = 0.0f;
+    int code = HIT_NONE, prim = -1;
     uint32_t nn = 0, nt = 0;
+    if (seg >= RT_NSEG_HALF && sc.deferred) {
+        // heavy rays: the whole wave walks together and tests queued leaves 64 at a time (lanes without a ray take part)
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
+        world_hit_deferred<COUNT, USE_LDS>(sc, lds_nodes, areas[threadIdx.x >> 6], il < n_seg, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+        if (il >= n_seg) return;
+    } else if (il >= n_seg) return;
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
-    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    else if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     hit[i] = make_float2(t_obj, __int_as_float(code));
@@ -663,11 +668,18 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     if (bx * BLOCK >= n) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0;
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
-    if (il >= n) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     uint32_t nn = 0, nt = 0;
-    const bool occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
-                           : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    bool occ;
+    if (seg >= RT_NSEG_HALF && sc.deferred) {
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
+        occ = world_occluded_deferred<COUNT, USE_LDS>(sc, lds_nodes, areas[threadIdx.x >> 6], il < n, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+        if (il >= n) return;
+    } else {
+        if (il >= n) return;
+        occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
+                    : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    }
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
@@ -798,7 +810,8 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long 
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
-static inline size_t lds_bytes(const DevScene &sc) { return top_cache_bytes(sc); }
+// dynamic LDS of the traversal kernels: the top of the tree (when cached) + one queue area per wave
+static inline size_t lds_bytes(const DevScene &sc, bool use_lds) { return wave_area_offset(sc, use_lds) + (BLOCK / 64) * sizeof(WaveWalkLds); }
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
 
@@ -819,9 +832,9 @@ void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-    else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-    else hipLaunchKernelGGL((k_extend<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    else hipLaunchKernelGGL((k_extend<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
@@ -844,9 +857,9 @@ void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-    else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-    else hipLaunchKernelGGL((k_shadow<false, false>), g, b, 0, cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    else hipLaunchKernelGGL((k_shadow<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
 }
 
 void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes,

@@ -3,11 +3,15 @@
 // THIS IS TEST INFRASTRUCTURE.  It is the checker for the HIP path and the timed CPU baseline; nothing in the
 // product may link, load or call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
 //
-// PARITY UNPINNED against the original binary: the reference holds no tests, golden vectors or fixtures, its Rust
-// toolchain is absent here (no cargo/rustc, crates not vendored) and its RNG is OS-seeded (rand::thread_rng), so no
-// output of the reference itself can be reproduced.  What pins this file instead: known-answer vectors derived by
-// hand from the reference source (tests/golden/kat.json) and a statistical comparison with the one committed render
-// whose scene is live at HEAD (output/microfacet.jpg region means, tests/golden/microfacet_regions.json).
+// What pins this file: the reference holds no tests or golden vectors, its Rust toolchain is absent here (no
+// cargo/rustc, crates not vendored) and its RNG is OS-seeded (rand::thread_rng), so its binary cannot be run or
+// reproduced sample by sample.  It does hold renders of scenes whose constructors are live at HEAD; reduced to data
+// fixtures (tests/golden/reference_renders.*, microfacet_regions.json, scripts beside them) they pin, pixel for pixel
+// where the reference's own run was deterministic (chess board, uniform sampler, point light) and by block / region
+// means elsewhere: camera, Mesh::transform's Euler convention, hit_list, triangles, spheres, cylinders, the Whitted and
+// MIS shaders, Diffuse, Metal and Microfacet, Point / Disk / Polygon lights, the four pixel samplers, the resolve.
+// PARITY UNPINNED (no render of the reference covers them; hand-derived known-answer vectors in tests/golden/kat.json
+// only): Dielectric, path_trace_shader, normal_shader, DiskLight::visible (the Whitted estimator of a disk light).
 //
 // Structure follows the reference file by file (citations are paths under the reference root):
 //   vector maths      cgmath 0.18.0 (Cargo.lock) — dot = (x*x'+y*y')+z*z', normalize = v * (1/|v|), lerp = a+(b-a)*t

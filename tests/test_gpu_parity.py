@@ -452,3 +452,30 @@ def test_largest_frame_and_the_limit(rt, orc, gpu_ctx):
         ds.render(hs.camera, rt.default_params(W, H + 1, 1))
     assert e.value.code == rt.RT_ERR_INVALID
     ds.close()
+
+
+# ---- the HIP path against renders the reference itself holds ----------------------------------------------------------
+def test_gpu_chess_board_matches_the_reference_render_pixel_for_pixel(rt, gpu_ctx, golden_dir):
+    """output/sampling/chessboard/9spp/uniform_9spp_8x.jpg (Scene::blue_noise_test, Whitted shader, uniform sampler, point
+    light: deterministic in the reference too), reduced to its 200x200 pixels: the GPU image agrees up to JPEG error."""
+    want = np.load(os.path.join(golden_dir, "reference_renders.npz"))["chess_uniform_9"].astype(np.float64)
+    hs = rt.HostScene("blue_noise_test", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    acc, _ = ds.render(hs.camera, rt.default_params(200, 200, 9, shader=rt.SHADER_WHITTED, pixel_sampler=rt.SAMPLER_UNIFORM))
+    got = rt.resolve(acc, 9)[1].astype(np.float64)
+    d = np.abs(got - want).max(axis=2)
+    assert d.mean() < 3.0 and (d > 24).mean() < 0.01, (d.mean(), (d > 24).mean())
+    ds.close()
+
+
+def test_gpu_light_scene_matches_the_reference_render(rt, gpu_ctx, golden_dir):
+    """output/sampling/mis/3light_400spp.jpg (Scene::light_test, MIS shader, three PolygonLights) as 40x40 block means;
+    the GPU renders the full 800x800 frame at 400 spp."""
+    want = np.load(os.path.join(golden_dir, "reference_renders.npz"))["light_test_400_grid40"].astype(np.float64)
+    hs = rt.HostScene("light_test", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    acc, _ = ds.render(hs.camera, rt.default_params(800, 800, 400, seed=2))
+    got = rt.resolve(acc, 400)[1].astype(np.float64).reshape(40, 20, 40, 20, 3).mean(axis=(1, 3))
+    d = np.abs(got - want).max(axis=2)
+    assert d.mean() < 1.0 and np.percentile(d, 95) < 3.0, (d.mean(), np.percentile(d, 95))
+    ds.close()

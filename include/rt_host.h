@@ -49,6 +49,17 @@ void rth_free(void *p);
  * from the raw integers of rt_resolve. */
 int32_t rth_write_ppm(const char *path, int32_t width, int32_t height, const int32_t *rgb_i32);
 
+/*
+ * Resumable accumulation.  The reference streams finished rows into its PPM (src/bin/main.rs:51), so a killed run
+ * leaves a truncated image; here a render is a sum buffer plus the number of samples already added to it
+ * (rt_render adds samples [spp_begin, spp_end) and never clears), which can be written out and picked up again.
+ * File: 32-byte header { char magic[8] = "RTACCUM1"; int32 width, height, spp, spp_done; uint32 seed, reserved }
+ * then width*height*3 little-endian floats.  rth_accum_load checks width, height, spp and seed against the values
+ * passed in (RT_ERR_INVALID on mismatch or a short file) and returns the samples done through *spp_done.
+ */
+int32_t rth_accum_save(const char *path, int32_t width, int32_t height, int32_t spp, int32_t spp_done, uint32_t seed, const float *accum_rgb);
+int32_t rth_accum_load(const char *path, int32_t width, int32_t height, int32_t spp, uint32_t seed, int32_t *spp_done, float *accum_rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,10 @@ def host_lib() -> C.CDLL:
         lib.rth_free.restype = None
         lib.rth_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, c_int32_p]
         lib.rth_write_ppm.restype = C.c_int32
+        lib.rth_accum_save.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, c_float_p]
+        lib.rth_accum_save.restype = C.c_int32
+        lib.rth_accum_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32), c_float_p]
+        lib.rth_accum_load.restype = C.c_int32
         _host = lib
     return _host
 
@@ -249,6 +253,25 @@ def write_ppm(path: str, rgb_i32: np.ndarray) -> None:
     rc = host_lib().rth_write_ppm(path.encode(), w, h, _ip(a))
     if rc != RT_OK:
         raise RtError(rc, host_lib().rth_last_error().decode())
+
+
+def save_accum(path: str, accum: np.ndarray, spp: int, spp_done: int, seed: int = 1) -> None:
+    """rth_accum_save: the sum buffer and the number of samples already in it, to be picked up by load_accum."""
+    h, w, _ = accum.shape
+    a = np.ascontiguousarray(accum, np.float32)
+    rc = host_lib().rth_accum_save(path.encode(), w, h, spp, spp_done, seed, _fp(a))
+    if rc != RT_OK:
+        raise RtError(rc, host_lib().rth_last_error().decode())
+
+
+def load_accum(path: str, width: int, height: int, spp: int, seed: int = 1) -> Tuple[np.ndarray, int]:
+    """rth_accum_load: (sum buffer, samples done); RtError if the file was saved for another frame, sample count or seed."""
+    a = np.empty((height, width, 3), np.float32)
+    done = C.c_int32()
+    rc = host_lib().rth_accum_load(path.encode(), width, height, spp, seed, C.byref(done), _fp(a))
+    if rc != RT_OK:
+        raise RtError(rc, host_lib().rth_last_error().decode())
+    return a, done.value
 
 
 # ----------------------------------------------------------------------------------------------- device library

@@ -621,4 +621,43 @@ int32_t rth_write_ppm(const char *path, int32_t w, int32_t h, const int32_t *rgb
     return RT_OK;
 }
 
+namespace {
+struct AccumHeader {
+    char magic[8];
+    int32_t width, height, spp, spp_done;
+    uint32_t seed, reserved;
+};
+static_assert(sizeof(AccumHeader) == 32, "accumulation file header is 32 bytes");
+} // namespace
+
+int32_t rth_accum_save(const char *path, int32_t w, int32_t h, int32_t spp, int32_t spp_done, uint32_t seed, const float *accum) {
+    if (!path || !accum || w <= 0 || h <= 0 || spp <= 0 || spp_done < 0 || spp_done > spp) { g_host_err = "rth_accum_save: bad argument"; return RT_ERR_INVALID; }
+    // written under a temporary name and renamed: a run killed while saving keeps the previous state
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) { g_host_err = std::string("cannot create ") + tmp; return RT_ERR_INVALID; }
+    AccumHeader hd{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'}, w, h, spp, spp_done, seed, 0u};
+    const size_t n = (size_t)w * (size_t)h * 3;
+    bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1 && std::fwrite(accum, sizeof(float), n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) { g_host_err = std::string("cannot write ") + path; std::remove(tmp.c_str()); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+int32_t rth_accum_load(const char *path, int32_t w, int32_t h, int32_t spp, uint32_t seed, int32_t *spp_done, float *accum) {
+    if (!path || !accum || !spp_done) { g_host_err = "rth_accum_load: bad argument"; return RT_ERR_INVALID; }
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { g_host_err = std::string("cannot open ") + path; return RT_ERR_INVALID; }
+    AccumHeader hd;
+    const size_t n = (size_t)w * (size_t)h * 3;
+    int32_t rc = RT_OK;
+    if (std::fread(&hd, sizeof(hd), 1, f) != 1 || std::memcmp(hd.magic, "RTACCUM1", 8) != 0) { g_host_err = std::string(path) + ": not an accumulation file"; rc = RT_ERR_INVALID; }
+    else if (hd.width != w || hd.height != h || hd.spp != spp || hd.seed != seed) { g_host_err = std::string(path) + ": saved for another frame size, sample count or seed"; rc = RT_ERR_INVALID; }
+    else if (hd.spp_done < 0 || hd.spp_done > hd.spp) { g_host_err = std::string(path) + ": bad sample count"; rc = RT_ERR_INVALID; }
+    else if (std::fread(accum, sizeof(float), n, f) != n) { g_host_err = std::string(path) + ": truncated"; rc = RT_ERR_INVALID; }
+    else *spp_done = hd.spp_done;
+    std::fclose(f);
+    return rc;
+}
+
 } // extern "C"

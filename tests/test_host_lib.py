@@ -130,3 +130,28 @@ def test_sharding_plans(rt):
         rt.plan_shards("rows", 0, 1, 16)
     with pytest.raises(ValueError):
         rt.plan_shards("spp", 2, 2, 16)
+
+
+def test_accumulation_files_round_trip_and_refuse_a_different_render(rt, tmp_path):
+    """rth_accum_save / rth_accum_load: the resumable state of a render is (sum buffer, samples done)."""
+    rng = np.random.default_rng(3)
+    a = rng.random((5, 7, 3), dtype=np.float32) * 40
+    a[0, 0, 0] = np.inf  # non-finite sums survive unchanged
+    path = str(tmp_path / "state.rtacc")
+    rt.save_accum(path, a, spp=64, spp_done=24, seed=9)
+    assert os.path.getsize(path) == 32 + a.size * 4 and not os.path.exists(path + ".tmp")
+    b, done = rt.load_accum(path, 7, 5, 64, seed=9)
+    assert done == 24 and np.array_equal(a, b)
+    for kw in ({"width": 8}, {"height": 6}, {"spp": 65}, {"seed": 10}):
+        args = dict(width=7, height=5, spp=64, seed=9)
+        args.update(kw)
+        with pytest.raises(rt.RtError, match="another frame size"):
+            rt.load_accum(path, **args)
+    with open(path, "r+b") as f:
+        f.truncate(100)
+    with pytest.raises(rt.RtError, match="truncated"):
+        rt.load_accum(path, 7, 5, 64, seed=9)
+    with pytest.raises(rt.RtError, match="cannot open"):
+        rt.load_accum(str(tmp_path / "missing"), 7, 5, 64, seed=9)
+    with pytest.raises(rt.RtError):
+        rt.save_accum(path, a, spp=64, spp_done=65, seed=9)

@@ -1,7 +1,8 @@
 // rtcli — command-line renderer: the counterpart of the reference's src/bin/main.rs on top of the GPU backend.
 //
 //   rtcli <light-sampler 1..4> [--scene head] [--width 800] [--height 800] [--spp 800] [--shader mis|path|whitted|normal]
-//         [--pixel-sampler 1..4] [--seed 1] [--device 0] [--assets assets] [--out ./output/out.ppm]
+//         [--pixel-sampler 1..4] [--seed 1] [--device 0] [--assets assets] [--out ./output/out.ppm] [--batch N]
+//         [--resume FILE] [--stop-after N]
 //
 // argv[1] keeps its meaning (SamplerKind::from_int for the light sampler, main.rs:15-18); the compile-time constants
 // NX, NY, NS of src/lib.rs:21-23 and the scene / shader chosen by (un)commenting code (main.rs:20-23,40-43) are
@@ -20,7 +21,9 @@
 
 static int usage() {
     std::fprintf(stderr, "usage: rtcli <light-sampler 1..4> [--scene NAME] [--width W] [--height H] [--spp N] [--shader mis|path|whitted|normal]\n"
-                         "             [--pixel-sampler 1..4] [--seed S] [--device D] [--assets DIR] [--out FILE] [--batch N]\n");
+                         "             [--pixel-sampler 1..4] [--seed S] [--device D] [--assets DIR] [--out FILE] [--batch N]\n"
+                         "             [--resume FILE: sums + samples done, saved after every batch, picked up if present]\n"
+                         "             [--stop-after N: leave after N samples per pixel (with --resume: continue later)]\n");
     return 2;
 }
 
@@ -28,8 +31,8 @@ int main(int argc, char **argv) {
     auto now = std::chrono::steady_clock::now();
     if (argc < 2) return usage();
     int light_sampler = std::atoi(argv[1]);
-    std::string scene = "head", shader = "mis", assets = "assets", out = "./output/out.ppm";
-    int width = 800, height = 800, spp = 800, pixel_sampler = RT_SAMPLER_BLUE, device = 0, batch = 0;
+    std::string scene = "head", shader = "mis", assets = "assets", out = "./output/out.ppm", resume;
+    int width = 800, height = 800, spp = 800, pixel_sampler = RT_SAMPLER_BLUE, device = 0, batch = 0, stop_after = 0;
     unsigned seed = 1;
     for (int i = 2; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
@@ -44,6 +47,8 @@ int main(int argc, char **argv) {
         else if (k == "--assets") assets = v;
         else if (k == "--out") out = v;
         else if (k == "--batch") batch = std::atoi(v.c_str());
+        else if (k == "--resume") resume = v;
+        else if (k == "--stop-after") stop_after = std::atoi(v.c_str());
         else return usage();
     }
     if (light_sampler < 1 || light_sampler > 4) { // SamplerKind::from_int, sampler.rs:13-21
@@ -72,9 +77,21 @@ int main(int argc, char **argv) {
     std::vector<float> accum((size_t)width * height * 3, 0.0f);
     if (batch <= 0) batch = spp < 16 ? spp : (spp + 15) / 16;
     unsigned long long rays = 0;
-    for (int b = 0; b < spp; b += batch) {
+    int done = 0;
+    if (!resume.empty()) {
+        if (FILE *probe = std::fopen(resume.c_str(), "rb")) {
+            std::fclose(probe);
+            if (rth_accum_load(resume.c_str(), width, height, spp, seed, &done, accum.data()) != RT_OK) {
+                std::fprintf(stderr, "Error: %s\n", rth_last_error());
+                return 1;
+            }
+            std::printf("Resuming at sample %d of %d\n", done, spp);
+        }
+    }
+    const int last = stop_after > 0 && stop_after < spp ? stop_after : spp;
+    for (int b = done; b < last; b += batch) {
         p.spp_begin = b;
-        p.spp_end = b + batch < spp ? b + batch : spp;
+        p.spp_end = b + batch < last ? b + batch : last;
         rt_stats st;
         if (rt_render(sc, rth_scene_camera(hs), &p, accum.data(), 0, &st) != RT_OK) {
             std::fprintf(stderr, "Error: %s\n", rt_last_error());
@@ -83,6 +100,17 @@ int main(int argc, char **argv) {
         rays += st.rays_closest + st.rays_shadow;
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - now).count();
         std::printf("Now rendering: %g%%, %lld seconds elapsed\n", (double)(p.spp_end * 100) / (double)spp, (long long)secs);
+        if (!resume.empty() && rth_accum_save(resume.c_str(), width, height, spp, p.spp_end, seed, accum.data()) != RT_OK) {
+            std::fprintf(stderr, "Error: %s\n", rth_last_error());
+            return 1;
+        }
+    }
+    if (last < spp) {
+        std::printf("Stopped after %d of %d samples.\n", last, spp);
+        rt_scene_destroy(sc);
+        rt_context_destroy(ctx);
+        rth_scene_destroy(hs);
+        return 0;
     }
     std::vector<int32_t> rgb((size_t)width * height * 3);
     rt_resolve(accum.data(), (int64_t)width * height, spp, rgb.data(), nullptr);

@@ -16,9 +16,20 @@ HOSTFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra
 
 all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so tools/rtcli oracle
 
-$(LIBDIR)/librt_hip.so: $(CSRC)/rt_kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/rt_bvh.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h include/rt_api.h
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/rt_kernels.hip -x hip $(CSRC)/rt_api.cpp $(CSRC)/rt_bvh.cpp
+OBJDIR := $(LIBDIR)/obj
+HIP_OBJS := $(OBJDIR)/rt_kernels.o $(OBJDIR)/rt_api.o $(OBJDIR)/rt_bvh.o $(OBJDIR)/rt_bvh_device.o
+HIP_HDRS := $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/rt_bvh.h $(CSRC)/rt_bvh_device.h include/rt_api.h
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
+
+$(LIBDIR)/librt_hip.so: $(HIP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(HIP_OBJS)
 
 $(LIBDIR)/librt_host.so: $(PKG)/host/rt_host.cpp $(PKG)/host/rt_host.hpp include/rt_host.h include/rt_api.h
 	@mkdir -p $(LIBDIR)

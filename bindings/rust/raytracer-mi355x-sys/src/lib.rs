@@ -35,6 +35,9 @@ pub const RT_ERR_NOMEM: i32 = 4;
     pub launches_extend: u64, pub launches_shade: u64, pub launches_shadow: u64, pub launches_raygen: u64,
     pub ms_total: f64, pub ms_extend: f64, pub ms_shade: f64, pub ms_shadow: f64, pub ms_raygen: f64,
     pub device_bytes: u64 }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct rt_scene_info { pub n_triangles: i32, pub n_nodes: i32, pub n_orders: i32,
+    pub n_top: i32, pub bvh_on_device: i32, pub reserved: i32, pub bvh_build_ms: f64 }
+pub const RT_SCENE_BVH_ON_DEVICE: u32 = 1;
 pub enum rt_context {}
 pub enum rt_scene {}
 
@@ -44,6 +47,8 @@ extern "C" {
     pub fn rt_context_destroy(ctx: *mut rt_context) -> i32;
     pub fn rt_scene_create(ctx: *mut rt_context, desc: *const rt_scene_desc, out: *mut *mut rt_scene) -> i32;
     pub fn rt_scene_destroy(scene: *mut rt_scene) -> i32;
+    pub fn rt_scene_create_ex(ctx: *mut rt_context, desc: *const rt_scene_desc, flags: u32, out: *mut *mut rt_scene) -> i32;
+    pub fn rt_scene_get_info(scene: *const rt_scene, info: *mut rt_scene_info) -> i32;
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_params, accum_rgb: *mut f32,
                      accum_is_device: i32, stats: *mut rt_stats) -> i32;
     pub fn rt_render_static(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_params, accum_rgb_dev: *mut f32,

@@ -158,6 +158,28 @@ int32_t rt_scene_create(rt_context *ctx, const rt_scene_desc *desc, rt_scene **o
 int32_t rt_scene_destroy(rt_scene *scene);
 
 /*
+ * rt_scene_create with flags.  RT_SCENE_BVH_ON_DEVICE: the acceleration structure is built on the GPU (Morton codes,
+ * radix sort, one thread per inner node, bottom-up refit) instead of on the host — the counterpart of
+ * BVHTree::build_tree (src/mesh.rs:225-261), which the reference re-runs after every Mesh::transform (src/mesh.rs:42).
+ * The tree differs from the host builder's (one triangle per leaf, 2n-1 nodes, no LDS-resident top); hits and images
+ * do not.  rt_scene_create is rt_scene_create_ex with flags 0 (or RT_SCENE_BVH_ON_DEVICE when RT_BVH_DEVICE=1 is set
+ * in the environment).
+ */
+enum { RT_SCENE_BVH_ON_DEVICE = 1 };
+int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *desc, uint32_t flags, rt_scene **out);
+
+typedef struct rt_scene_info {
+    int32_t n_triangles;
+    int32_t n_nodes;       /* per visiting order */
+    int32_t n_orders;      /* 8 = one link set per direction octant, 1 = a single order */
+    int32_t n_top;         /* nodes kept in LDS by the traversal kernels */
+    int32_t bvh_on_device; /* built by the GPU builder */
+    int32_t reserved;
+    double bvh_build_ms;   /* wall time of the build, uploads / downloads included */
+} rt_scene_info;
+int32_t rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);
+
+/*
  * Replaces the pixel x sample loop of src/bin/main.rs:28-44: adds the radiance of samples [spp_begin,spp_end) of
  * every selected pixel into accum_rgb (width*height*3 floats, row 0 = top image row, i.e. j = height-1 of the
  * reference loop).  accum_rgb is a device pointer if accum_is_device != 0, else host memory (read, added to,

@@ -29,6 +29,7 @@ SAMPLER_WHITE, SAMPLER_UNIFORM, SAMPLER_JITTERED, SAMPLER_BLUE = 1, 2, 3, 4
 OBJ_TRIANGLE, OBJ_SPHERE, OBJ_CYLINDER, OBJ_MESH = 0, 1, 2, 3
 SHADER_NORMAL, SHADER_WHITTED, SHADER_PATH, SHADER_MIS = 0, 1, 2, 3
 FLAG_TIMING, FLAG_COUNT_WORK = 1, 2
+SCENE_BVH_ON_DEVICE = 1
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -67,6 +68,11 @@ class Params(C.Structure):
                 ("spp_end", C.c_int32), ("tile_size", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
                 ("shader", C.c_int32), ("pixel_sampler", C.c_int32), ("light_samples", C.c_int32), ("max_depth", C.c_int32),
                 ("t_min", C.c_float), ("t_max", C.c_float), ("seed", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_orders", C.c_int32), ("n_top", C.c_int32),
+                ("bvh_on_device", C.c_int32), ("reserved", C.c_int32), ("bvh_build_ms", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -317,6 +323,10 @@ def hip_lib() -> C.CDLL:
         lib.rt_context_destroy.restype = C.c_int32
         lib.rt_scene_create.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         lib.rt_scene_create.restype = C.c_int32
+        lib.rt_scene_create_ex.argtypes = [C.c_void_p, C.POINTER(SceneDesc), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rt_scene_create_ex.restype = C.c_int32
+        lib.rt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        lib.rt_scene_get_info.restype = C.c_int32
         lib.rt_scene_destroy.argtypes = [C.c_void_p]
         lib.rt_scene_destroy.restype = C.c_int32
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_int32, C.POINTER(Stats)]
@@ -392,12 +402,21 @@ class Context:
 class DeviceScene:
     """Scene uploaded to the GPU (rt_scene_create): BVH built, buffers resident."""
 
-    def __init__(self, ctx: Context, desc: SceneDesc, keepalive=None):
+    def __init__(self, ctx: Context, desc: SceneDesc, keepalive=None, bvh_on_device: Optional[bool] = None):
         self.ctx = ctx
         self._keep = keepalive
         self._h = C.c_void_p()
-        _check(hip_lib().rt_scene_create(ctx._h, C.byref(desc), C.byref(self._h)))
+        if bvh_on_device is None:  # rt_scene_create: host builder unless RT_BVH_DEVICE=1
+            _check(hip_lib().rt_scene_create(ctx._h, C.byref(desc), C.byref(self._h)))
+        else:
+            _check(hip_lib().rt_scene_create_ex(ctx._h, C.byref(desc), SCENE_BVH_ON_DEVICE if bvh_on_device else 0, C.byref(self._h)))
         ctx._scenes.add(self)
+
+    @property
+    def info(self) -> SceneInfo:
+        i = SceneInfo()
+        _check(hip_lib().rt_scene_get_info(self._h, C.byref(i)))
+        return i
 
     def render(self, cam: Camera, params: Params, accum: Optional[np.ndarray] = None) -> Tuple[np.ndarray, Stats]:
         """Adds the selected samples into a host (H, W, 3) float32 sum buffer (created zeroed if None)."""

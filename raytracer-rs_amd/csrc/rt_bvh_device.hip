@@ -1,0 +1,296 @@
+// rt_bvh_device.hip — the acceleration structure built on the GPU (gfx950).
+//
+// Takes the place of BVHTree::build_tree (src/mesh.rs:225-261), which the reference runs on the CPU after every
+// Mesh::transform (src/mesh.rs:42): a linear BVH over all world triangles — Morton codes of the triangle centroids,
+// one radix sort, one thread per inner node finding its range and split from the sorted codes (Karras 2012), a bottom-up
+// refit — emitted in the layout the traversal kernels walk (rt_device.h): threaded nodes with hit and miss links, one
+// copy of the links per sign octant of the ray direction, triangles in leaf order.  One triangle per leaf; node index
+// i in [0, n-1) is inner node i (0 = root), n-1+j is the leaf of the j-th triangle in sorted order.  The tree's shape
+// differs from the host builder's (binned SAH, rt_bvh.cpp); results cannot: boxes only cull, the exact triangle tests
+// and the tie rule are the kernels'.
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+
+#include "rt_bvh_device.h"
+
+namespace rtd {
+namespace {
+
+#define BB 256
+
+__device__ __forceinline__ int order_int(float f) { // monotonic float -> int
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float order_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+struct Box6 {
+    float mn[3], mx[3];
+};
+
+// padded box of every triangle (same padding as the host builder: the exact triangle test may accept a hit a rounding
+// error outside the exact box, and flat axis-aligned faces have zero-thickness boxes) + bounds of the centroids
+__global__ __launch_bounds__(BB) void k_bvh_prepare(const float *tri_v, int n, Box6 *tbox, float *centroid, int *bounds /* min xyz, max xyz as ordered ints */) {
+    __shared__ int s_b[6];
+    if (threadIdx.x < 3) s_b[threadIdx.x] = 0x7FFFFFFF;
+    else if (threadIdx.x < 6) s_b[threadIdx.x] = (int)0x80000000;
+    __syncthreads();
+    const int t = blockIdx.x * BB + threadIdx.x;
+    if (t < n) {
+        const float *v = tri_v + 9 * (size_t)t;
+        Box6 b;
+        float ext = 0.0f, mag = 0.0f;
+        for (int a = 0; a < 3; a++) {
+            b.mn[a] = fminf(fminf(v[a], v[3 + a]), v[6 + a]);
+            b.mx[a] = fmaxf(fmaxf(v[a], v[3 + a]), v[6 + a]);
+            ext = fmaxf(ext, b.mx[a] - b.mn[a]);
+            mag = fmaxf(mag, fmaxf(fabsf(b.mn[a]), fabsf(b.mx[a])));
+        }
+        const float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+        for (int a = 0; a < 3; a++) {
+            b.mn[a] -= pad;
+            b.mx[a] += pad;
+            const float c = (v[a] + v[3 + a] + v[6 + a]) * (1.0f / 3.0f);
+            centroid[3 * (size_t)t + a] = c;
+            atomicMin(&s_b[a], order_int(c));
+            atomicMax(&s_b[3 + a], order_int(c));
+        }
+        tbox[t] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) { // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// key = 30-bit Morton code of the centroid << 32 | triangle index: unique, so equal codes need no special case
+__global__ __launch_bounds__(BB) void k_bvh_keys(const float *centroid, int n, const int *bounds, unsigned long long *keys) {
+    const int t = blockIdx.x * BB + threadIdx.x;
+    if (t >= n) return;
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = order_float(bounds[a]), hi = order_float(bounds[3 + a]);
+        const float ext = hi - lo;
+        float u = ext > 0.0f ? (centroid[3 * (size_t)t + a] - lo) / ext : 0.0f;
+        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        q[a] = (uint32_t)u;
+    }
+    const uint32_t code = (spread3(q[0]) << 2) | (spread3(q[1]) << 1) | spread3(q[2]);
+    keys[t] = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)t;
+}
+
+// triangle records in sorted (= leaf) order: (v0, prim), (v1 - v0, material), (v2 - v0, 0) — geometry.rs:30-31's two
+// subtractions, done once; leaf boxes in node-index space
+__global__ __launch_bounds__(BB) void k_bvh_emit_tris(const float *tri_v, const int32_t *prim, const int32_t *mat, const unsigned long long *keys, int n,
+                                                      const Box6 *tbox, float4 *tris, Box6 *nbox) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = (uint32_t)keys[i];
+    const float *v = tri_v + 9 * (size_t)t;
+    tris[3 * (size_t)i] = make_float4(v[0], v[1], v[2], __int_as_float(prim[t]));
+    tris[3 * (size_t)i + 1] = make_float4(v[3] - v[0], v[4] - v[1], v[5] - v[2], __int_as_float(mat[t]));
+    tris[3 * (size_t)i + 2] = make_float4(v[6] - v[0], v[7] - v[1], v[8] - v[2], 0.0f);
+    nbox[(size_t)(n - 1) + i] = tbox[t];
+}
+
+__device__ __forceinline__ int common_prefix(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+// one thread per inner node: its range of sorted keys and where the range splits (highest differing bit)
+__global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *keys, int n, int2 *children, int *parent) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = common_prefix(keys, n, i, i - d);
+    int lmax = 2;
+    while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (common_prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = common_prefix(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (common_prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int left = min(i, j) == gamma ? (n - 1) + gamma : gamma;
+    const int right = max(i, j) == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
+    children[i] = make_int2(left, right);
+    parent[left] = i;
+    parent[right] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+// bottom-up: the second thread to arrive at an inner node owns it.  Release before the counter, acquire after it: the
+// children's boxes were written by other compute units.
+__global__ __launch_bounds__(BB) void k_bvh_refit(int n, const int2 *children, const int *parent, int *arrived, Box6 *nbox) {
+    const int j = blockIdx.x * BB + threadIdx.x;
+    if (j >= n) return;
+    int cur = parent[(n - 1) + j];
+    while (cur >= 0) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1) == 0) return;
+        __threadfence();
+        const int2 c = children[cur];
+        const volatile Box6 *a = &nbox[c.x], *b = &nbox[c.y];
+        Box6 u;
+        for (int k = 0; k < 3; k++) {
+            u.mn[k] = fminf(a->mn[k], b->mn[k]);
+            u.mx[k] = fmaxf(a->mx[k], b->mx[k]);
+        }
+        nbox[cur] = u;
+        cur = parent[cur];
+    }
+}
+
+// for every inner node and direction octant: is the right child visited first?  Same key as the host builder: children
+// sorted along the octant's diagonal, the side the ray comes from first; equal keys keep (left, right).
+__global__ __launch_bounds__(BB) void k_bvh_order(int n, const int2 *children, const Box6 *nbox, unsigned char *swap_mask) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int2 c = children[i];
+    const Box6 a = nbox[c.x], b = nbox[c.y];
+    uint32_t m = 0;
+    for (int k = 0; k < 8; k++) {
+        float ka = 0.0f, kb = 0.0f;
+        for (int ax = 0; ax < 3; ax++) {
+            const float sgn = (k >> ax) & 1 ? -1.0f : 1.0f;
+            ka += sgn * (a.mn[ax] + a.mx[ax]);
+            kb += sgn * (b.mn[ax] + b.mx[ax]);
+        }
+        if (kb < ka) m |= 1u << k;
+    }
+    swap_mask[i] = (unsigned char)m;
+}
+
+// the threaded node arrays: node `idx` of order k gets its box, its hit link (first child in that order, or the
+// leaf's triangle) and its miss link (where the walk goes on after the node's subtree: up until the node is a first
+// child, then across to the second)
+__global__ __launch_bounds__(BB) void k_bvh_thread(int n, int n_orders, const int2 *children, const int *parent, const unsigned char *swap_mask,
+                                                   const Box6 *nbox, float4 *nodes) {
+    const int nn = 2 * n - 1;
+    const long long g = (long long)blockIdx.x * BB + threadIdx.x;
+    if (g >= (long long)nn * n_orders) return;
+    const int k = (int)(g / nn), idx = (int)(g - (long long)k * nn);
+    const int ko = n_orders == 8 ? k : 0; // a single order: the one of octant 0
+    int link;
+    if (idx < n - 1) {
+        const int2 c = children[idx];
+        link = (swap_mask[idx] >> ko) & 1 ? c.y : c.x;
+    } else {
+        link = ~((idx - (n - 1)) * 8);
+    }
+    int miss = -1, cur = idx;
+    for (int p = parent[cur]; p >= 0; p = parent[cur]) {
+        const int2 c = children[p];
+        const bool sw = (swap_mask[p] >> ko) & 1;
+        const int first = sw ? c.y : c.x, second = sw ? c.x : c.y;
+        if (cur == first) { miss = second; break; }
+        cur = p;
+    }
+    const Box6 b = nbox[idx];
+    float4 *dst = nodes + 2 * ((size_t)k * (size_t)nn + (size_t)idx);
+    dst[0] = make_float4(b.mn[0], b.mx[0], b.mn[1], b.mx[1]);
+    dst[1] = make_float4(b.mn[2], b.mx[2], __int_as_float(link), __int_as_float(miss));
+}
+
+__global__ void k_bvh_init_bounds(int *bounds) {
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7FFFFFFF;
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
+}
+
+inline unsigned grid_for(long long n) { return (unsigned)((n + BB - 1) / BB); }
+
+} // namespace
+
+#define BVH_TRY(expr)                 \
+    do {                              \
+        hipError_t e_ = (expr);       \
+        if (e_ != hipSuccess) {       \
+            cleanup();                \
+            return e_;                \
+        }                             \
+    } while (0)
+
+hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const int32_t *prim_host, const int32_t *mat_host, int n, bool ordered,
+                            float4 *nodes_dev, float4 *tris_dev, uint32_t *order_host) {
+    if (n <= 0) return hipSuccess;
+    const int nn = 2 * n - 1, n_orders = ordered ? 8 : 1;
+    float *tri_v = nullptr, *centroid = nullptr;
+    int32_t *prim = nullptr, *mat = nullptr;
+    Box6 *tbox = nullptr, *nbox = nullptr;
+    unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+    int *bounds = nullptr, *parent = nullptr, *arrived = nullptr;
+    int2 *children = nullptr;
+    unsigned char *swap_mask = nullptr;
+    void *sort_tmp = nullptr;
+    auto cleanup = [&]() {
+        for (void *p : {(void *)tri_v, (void *)centroid, (void *)prim, (void *)mat, (void *)tbox, (void *)nbox, (void *)keys_in, (void *)keys_out, (void *)bounds,
+                        (void *)parent, (void *)arrived, (void *)children, (void *)swap_mask, sort_tmp})
+            if (p) (void)hipFree(p);
+    };
+    BVH_TRY(hipMalloc((void **)&tri_v, 9 * sizeof(float) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&prim, sizeof(int32_t) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&mat, sizeof(int32_t) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&centroid, 3 * sizeof(float) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&tbox, sizeof(Box6) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&nbox, sizeof(Box6) * (size_t)nn));
+    BVH_TRY(hipMalloc((void **)&keys_in, sizeof(unsigned long long) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&keys_out, sizeof(unsigned long long) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&bounds, 6 * sizeof(int)));
+    BVH_TRY(hipMalloc((void **)&parent, sizeof(int) * (size_t)nn));
+    BVH_TRY(hipMalloc((void **)&arrived, sizeof(int) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&children, sizeof(int2) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&swap_mask, (size_t)n));
+    size_t sort_bytes = 0;
+    BVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys_out, n, 0, 62, stream));
+    BVH_TRY(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
+
+    BVH_TRY(hipMemcpyAsync(tri_v, tri_v_host, 9 * sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemcpyAsync(prim, prim_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemcpyAsync(mat, mat_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
+    BVH_TRY(hipMemsetAsync(arrived, 0, sizeof(int) * (size_t)n, stream));
+    hipLaunchKernelGGL(k_bvh_init_bounds, dim3(1), dim3(64), 0, stream, bounds);
+    hipLaunchKernelGGL(k_bvh_prepare, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, n, tbox, centroid, bounds);
+    hipLaunchKernelGGL(k_bvh_keys, dim3(grid_for(n)), dim3(BB), 0, stream, centroid, n, bounds, keys_in);
+    BVH_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys_in, keys_out, n, 0, 62, stream));
+    hipLaunchKernelGGL(k_bvh_emit_tris, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, prim, mat, keys_out, n, tbox, tris_dev, nbox);
+    if (n > 1) {
+        hipLaunchKernelGGL(k_bvh_hierarchy, dim3(grid_for(n - 1)), dim3(BB), 0, stream, keys_out, n, children, parent);
+        hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox);
+        hipLaunchKernelGGL(k_bvh_order, dim3(grid_for(n - 1)), dim3(BB), 0, stream, n, children, nbox, swap_mask);
+    } else {
+        const int minus_one = -1;
+        BVH_TRY(hipMemcpyAsync(parent, &minus_one, sizeof(int), hipMemcpyHostToDevice, stream));
+        BVH_TRY(hipStreamSynchronize(stream)); // minus_one goes out of scope
+    }
+    hipLaunchKernelGGL(k_bvh_thread, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, nbox, nodes_dev);
+    BVH_TRY(hipGetLastError());
+    // the sorted order goes back to the host: it needs to know where each triangle's record went
+    static_assert(sizeof(unsigned long long) == 8, "64-bit keys");
+    unsigned long long *keys_host = nullptr;
+    BVH_TRY(hipHostMalloc((void **)&keys_host, sizeof(unsigned long long) * (size_t)n, hipHostMallocDefault));
+    hipError_t e = hipMemcpyAsync(keys_host, keys_out, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess)
+        for (int i = 0; i < n; i++) order_host[i] = (uint32_t)keys_host[i];
+    (void)hipHostFree(keys_host);
+    cleanup();
+    return e;
+}
+
+} // namespace rtd

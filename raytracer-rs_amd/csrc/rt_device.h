@@ -137,6 +137,9 @@ struct DevScene {
     // loop the whole wave runs together (the reference's own scan of the world list, hitable.rs:44-50) instead of walking the BVH.
     const float4 *loose;
     int32_t n_loose;
+    // light shadow rays (they can only meet the loose triangles, spheres and cylinders) are answered by the shading
+    // kernel itself instead of going through the shadow queue when set (and n_loose >= 0)
+    int32_t inline_shadow;
     // heavy rays: exact triangle tests are queued per wave and run 64 at a time (bvh_traverse_deferred) when set
     int32_t deferred;
     const int32_t *tri_of_prim; // primitive id -> index into tris (-1 for spheres and cylinders)

@@ -67,6 +67,7 @@ struct Ctl {
     SegCounter seg_out[RT_NSEG];    // nodes appended per segment of the next queue
     SegCounter seg_shadow[RT_NSEG]; // shadow rays per segment, being filled by k_shade
     uint32_t seg_shadow_cur[RT_NSEG]; // ... of the previous iteration, being consumed by k_shadow
+    SegCounter seg_inline[RT_NSEG_HALF]; // occlusion queries k_shade answered itself (never queued), per producing segment
 };
 
 struct LaunchCfg {

@@ -80,14 +80,16 @@ __device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)
 // shadow rays in few cache lines.  The waves of the workgroup are ordered by an LDS counter, and one returning global
 // atomic per non-empty group reserves the workgroup's slots.  Every thread must call it.
 struct BlockAppendSeg {
-    uint32_t cnt[4];
+    uint32_t cnt[5];
     uint32_t base[4];
 };
 
-__device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const bool (&heavy)[3], uint32_t seg_l,
-                                                 uint32_t (&slot)[3]) {
+// `answered` = this lane's occlusion query was answered in place (counted for the statistics, no slot)
+__device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const bool (&heavy)[3], bool answered,
+                                                 uint32_t seg_l, uint32_t (&slot)[3]) {
     const uint32_t lane = threadIdx.x & 63u;
-    if (threadIdx.x < 4u) sm.cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 5u) sm.cnt[threadIdx.x] = 0u;
+    const uint32_t n_answered = (uint32_t)__popcll(__ballot(answered));
     unsigned long long m[3][2];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -99,11 +101,12 @@ __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, c
     const uint32_t cnt2 = (uint32_t)__popcll(m[2][0]), cnt3 = (uint32_t)__popcll(m[2][1]);
     __syncthreads();
     uint32_t wave_base = 0;
-    if (lane < 4u) {
-        const uint32_t c = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : cnt3;
+    if (lane < 5u) {
+        const uint32_t c = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : lane == 3u ? cnt3 : n_answered;
         if (c) wave_base = atomicAdd(&sm.cnt[lane], c);
     }
     __syncthreads();
+    if (threadIdx.x == 4u && sm.cnt[4] != 0u) atomicAdd(&ctl->seg_inline[seg_l].v, sm.cnt[4]);
     if (threadIdx.x < 4u) {
         const uint32_t c = sm.cnt[threadIdx.x];
         uint32_t *counter = threadIdx.x == 0u ? &ctl->seg_out[seg_l].v : threadIdx.x == 1u ? &ctl->seg_out[RT_NSEG_HALF + seg_l].v
@@ -170,8 +173,12 @@ __device__ __forceinline__ Node load_node(const NodeQueue &q, uint32_t i) {
 // ---- k_plan ---------------------------------------------------------------------------------------------------------
 __global__ void k_plan(Ctl *ctl, uint32_t target) {
     if (blockIdx.x != 0) return;
-    __shared__ uint32_t s_in[RT_NSEG], s_out[RT_NSEG], s_sh[RT_NSEG];
+    __shared__ uint32_t s_in[RT_NSEG], s_out[RT_NSEG], s_sh[RT_NSEG], s_inl[RT_NSEG_HALF];
     const uint32_t t = threadIdx.x;
+    if (t < RT_NSEG_HALF) {
+        s_inl[t] = ctl->seg_inline[t].v;
+        ctl->seg_inline[t].v = 0;
+    }
     if (t < RT_NSEG) {
         s_in[t] = ctl->seg_in[t].v;
         s_out[t] = ctl->seg_out[t].v;
@@ -196,6 +203,7 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     // close the iteration that just ran: it extended prev_in nodes, n_alive of which were carried in, the rest new camera rays
     h.rays_closest += prev_in;
     h.rays_shadow += prev_shadow;
+    for (int k = 0; k < RT_NSEG_HALF; k++) h.rays_shadow += s_inl[k];
     h.cam_samples += prev_in - h.n_alive;
     unsigned long long remaining = h.total - h.cursor;
     uint32_t n_new = 0;
@@ -570,11 +578,23 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const bool heavy1 = have1 && ray_is_heavy(sc, c1.o, c1.d, rc.t_min, rc.t_max);
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
     const bool heavy_s = nee && ray_is_heavy(sc, s_o, s_d, rc.t_min, 1.0f - rc.t_min);
-    const bool valid3[3] = {have0, have1, nee};
+    // A light occlusion query is a scan of the few loose triangles (and the spheres and cylinders): answered here, it
+    // costs neither the 40-byte store, nor the occlusion kernel's 40-byte load, nor a slot in the shadow queue.
+    bool answered = false;
+    if (SHADER != RT_SHADER_WHITTED && sc.inline_shadow && sc.n_loose >= 0) {
+        answered = nee && !heavy_s;
+        if (__ballot(answered) != 0ull) {
+            uint32_t nn = 0, nt = 0;
+            const bool occ = answered && world_occluded<false, false, true>(sc, nullptr, s_o, s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+            if (answered && !occ) add_pixel(planes, n_pixels, s_pixel, s_c);
+        }
+    }
+    const bool queued = nee && !answered;
+    const bool valid3[3] = {have0, have1, queued};
     const bool heavy3[3] = {heavy0, heavy1, heavy_s};
     const uint32_t seg3[3] = {ray_segment(heavy0, oseg_l), ray_segment(heavy1, oseg_l), ray_segment(heavy_s, oseg_l)};
     uint32_t slot[3];
-    block_append_seg(sm, ctl, valid3, heavy3, oseg_l, slot);
+    block_append_seg(sm, ctl, valid3, heavy3, answered, oseg_l, slot);
     if (have0) {
         if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0); else ctl->h.overflow = 1;
     }
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
             }
         }
     } else {
-        if (have_s) {
+        if (queued) {
             const uint32_t slot_s = slot[2];
             if (slot_s < shadow_seg_capacity) {
                 const uint32_t si = seg3[2] * shadow_seg_capacity + slot_s;

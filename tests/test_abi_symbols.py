@@ -25,7 +25,7 @@ def test_exports(header, lib):
 
 def test_expected_entry_points_are_declared():
     api = declared_functions("rt_api.h")
-    for n in ("rt_last_error", "rt_context_create", "rt_context_destroy", "rt_scene_create", "rt_scene_destroy", "rt_render",
+    for n in ("rt_last_error", "rt_context_create", "rt_context_destroy", "rt_scene_create", "rt_scene_create_ex", "rt_scene_get_info", "rt_scene_destroy", "rt_render",
               "rt_render_static", "rt_primary_hits", "rt_resolve", "rt_resolve_device", "rt_context_stream", "rt_params_default", "rt_bvh_build_host"):
         assert n in api
 
@@ -76,7 +76,7 @@ def test_rust_sys_declarations_follow_the_header(rt):
     assert fns == declared_functions("rt_api.h")
     rust_type = {C.c_int32: "i32", C.c_uint32: "u32", C.c_float: "f32", C.c_uint64: "u64", C.c_double: "f64"}
     for name, cls in (("rt_material", rt.Material), ("rt_light", rt.Light), ("rt_object", rt.Object), ("rt_scene_desc", rt.SceneDesc),
-                      ("rt_camera", rt.Camera), ("rt_params", rt.Params), ("rt_stats", rt.Stats)):
+                      ("rt_camera", rt.Camera), ("rt_params", rt.Params), ("rt_stats", rt.Stats), ("rt_scene_info", rt.SceneInfo)):
         body = re.search(r"pub struct %s\s*\{(.*?)\}" % name, src, flags=re.S).group(1)
         fields = re.findall(r"pub ([a-z0-9_]+)\s*:\s*([^,]+?)\s*(?:,|$)", body.replace("\n", " "))
         assert [f for f, _ in fields] == [f[0] for f in cls._fields_], name

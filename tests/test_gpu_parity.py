@@ -151,7 +151,7 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
     ds.close()
 
 
-KNOBS = [{"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
+KNOBS = [{"RT_DEFERRED": "0"}, {"RT_INLINE_SHADOW": "0"}, {"RT_INLINE_SHADOW": "2"}, {"RT_INLINE_SHADOW": "2", "RT_LOOSE_MAX": "0"}, {"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
          {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"}]
 
 
@@ -479,3 +479,56 @@ def test_gpu_light_scene_matches_the_reference_render(rt, gpu_ctx, golden_dir):
     d = np.abs(got - want).max(axis=2)
     assert d.mean() < 1.0 and np.percentile(d, 95) < 3.0, (d.mean(), np.percentile(d, 95))
     ds.close()
+
+
+# ---- the acceleration structure built on the GPU ------------------------------------------------------------------------
+@pytest.mark.parametrize("scene,W,H", [("utah", 160, 90), ("miku", 160, 90), ("composite", 96, 54), ("blue_noise_test", 64, 64), ("head", 48, 48)])
+def test_device_built_bvh_gives_the_same_hits_and_image(rt, orc, gpu_ctx, scene, W, H):
+    """rt_scene_create_ex(RT_SCENE_BVH_ON_DEVICE) — BVHTree::build_tree (src/mesh.rs:225-261) on the GPU: another tree
+    (one triangle per leaf, 2n-1 nodes), the same closest hits as the host-built tree and the oracle, bit for bit, and
+    the same image."""
+    hs = rt.HostScene(scene, W / H)
+    host = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=False)
+    dev = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=True)
+    n = hs.desc.n_tri
+    assert (host.info.bvh_on_device, dev.info.bvh_on_device) == (0, 1)
+    assert dev.info.n_triangles == n and dev.info.n_nodes == 2 * n - 1 and dev.info.n_orders == 8 and dev.info.n_top == 0
+    assert dev.info.bvh_build_ms > 0 and host.info.n_nodes <= dev.info.n_nodes
+    p = rt.default_params(W, H, 2, seed=4)
+    hp, ht = host.primary_hits(hs.camera, p)
+    dp, dt = dev.primary_hits(hs.camera, p)
+    assert np.array_equal(hp, dp) and np.array_equal(ht, dt)
+    cp, ct = orc.OracleScene(hs.desc, 1).primary_hits(hs.camera, p)
+    assert np.array_equal(dp, cp) and np.array_equal(dt, ct)
+    shader = rt.SHADER_WHITTED if scene == "blue_noise_test" else rt.SHADER_MIS
+    p = rt.default_params(W, H, 2, seed=4, shader=shader)
+    da, dst = dev.render(hs.camera, p)
+    ha, hst = host.render(hs.camera, p)
+    assert (dst.rays_closest, dst.rays_shadow) == (hst.rays_closest, hst.rays_shadow)
+    assert_radiance_close(da, ha, rel=1e-5)
+    ca, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, p)
+    assert_radiance_close(da, ca)
+    host.close()
+    dev.close()
+
+
+def test_device_built_bvh_edge_cases(rt, orc, gpu_ctx):
+    """One triangle (no inner node), two identical triangles (equal Morton codes; the later one wins the tie), the
+    axis-aligned cube (flat boxes), and an empty world."""
+    cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    tri = [-1, -1, -3, 1, -1, -3, 0, 1, -3]
+    cube = rt.load_obj(os.path.join(rt.ASSET_DIR, "cube.obj")) * np.float32(0.2) + np.tile(np.array([-0.3, -0.4, -3.0], np.float32), 3)
+    for tri_v in ([tri], [tri, tri], cube, None):
+        n = 0 if tri_v is None else len(tri_v)
+        sc = rt.NumpyScene(tri_v=tri_v, tri_mat=[0] * n, mats=[rt.diffuse(0.8, 0.8, 0.8)], lights=[rt.Light(rt.LIGHT_POINT, (0, 0.5, 0), 0, (3, 3, 3), 0, 0, 1)])
+        ds = rt.DeviceScene(gpu_ctx, sc.desc, sc, bvh_on_device=True)
+        p = rt.default_params(64, 64, 1)
+        gp, gt = ds.primary_hits(cam, p)
+        cp, ct = orc.OracleScene(sc.desc, 0, sc).primary_hits(cam, p)
+        assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+        if n == 2:
+            assert set(np.unique(gp)) == {-1, 1}
+        ga, _ = ds.render(cam, p)
+        ca, _ = orc.OracleScene(sc.desc, 0, sc).render(cam, p)
+        assert_radiance_close(ga, ca)
+        ds.close()

@@ -624,6 +624,8 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         UP(s->tri_of_prim, tri_of_prim.data(), tri_of_prim.size(), int32_t);
         s->dev.tri_of_prim = s->tri_of_prim.p;
         s->dev.deferred = env_u32_allow_zero("RT_DEFERRED", 1) != 0 ? 1 : 0;
+        s->dev.walk_span = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_SPAN", 4));
+        s->dev.walk_refill = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_REFILL", 32));
         s->dev.inline_shadow = (int32_t)env_u32_allow_zero("RT_INLINE_SHADOW", 1); // 0 never, 1 when it pays (see the render loop), 2 always
     }
 #undef UP

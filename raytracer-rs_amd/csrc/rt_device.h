@@ -140,8 +140,10 @@ struct DevScene {
     // light shadow rays (they can only meet the loose triangles, spheres and cylinders) are answered by the shading
     // kernel itself instead of going through the shadow queue when set (and n_loose >= 0)
     int32_t inline_shadow;
-    // heavy rays: exact triangle tests are queued per wave and run 64 at a time (bvh_traverse_deferred) when set
+    // heavy rays: exact triangle tests are queued per wave and run 64 at a time (walk_range) when set
     int32_t deferred;
+    int32_t walk_span; // ... and a wave may own up to 64 * walk_span consecutive rays of a heavy segment
+    int32_t walk_refill; // lanes that must be out of work before the wave retires their rays and hands out new ones
     const int32_t *tri_of_prim; // primitive id -> index into tris (-1 for spheres and cylinders)
     float heavy_min[4][3];
     float heavy_max[4][3];
@@ -431,42 +433,55 @@ __device__ __forceinline__ uint32_t float_order_key(float t) { // monotonic floa
 __device__ __forceinline__ float float_from_order_key(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
 }
+// wave-uniform values kept in scalar registers: tells the compiler what the control flow of the walk relies on
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-// Every lane of the wave must call it (valid = false for lanes without a ray); `wl` is the calling wave's own area.
-// Returns prim = primitive id of the closest hit (-1 = none) and tri = -1; the caller maps prim to the triangle record.
-template <bool ANY_HIT, bool COUNT, bool USE_LDS>
-__device__ __forceinline__ TriHit bvh_traverse_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
-                                                        float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
-    TriHit best{t_max, -1, -1};
-    if (sc.n_nodes == 0) return best;
+// A wave owns a RANGE of rays [first, first + total), usually more than 64: a lane whose ray is finished (walk done
+// and none of its leaves left in the queue) hands its result to the client and takes the next ray of the range, so the
+// lanes of a wave stay busy although their walks differ in length by an order of magnitude.  Lanes are retired and
+// refilled sc.walk_refill at a time (retiring and starting a ray costs the whole wave about 150 instructions) or when
+// nothing is left to do.
+//
+// Client (one per kernel):  bool fetch(uint32_t k, F3 *o, F3 *d)  loads ray k; false = already decided, no walk
+//                           void done(uint32_t k, F3 o, F3 d, const TriHit &h)   closest hit: h.prim (-1 = none), h.t;
+//                                                                                 occlusion query: h.tri >= 0 = occluded
+// Every lane of the wave must call walk_range; `wl` is the calling wave's own area.
+template <bool ANY_HIT, bool COUNT, bool USE_LDS, class Client>
+__device__ __forceinline__ void walk_range(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, Client &client, uint32_t first, uint32_t total,
+                                           float t_min, float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t NONE = 0xFFFFFFFFu;
     const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 32u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
-    const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
-    const f32x2 ix2 = {ix, ix}, iy2 = {iy, iy}, iz2 = {iz, iz};
-    const f32x2 ox2 = {-o.x * ix, -o.x * ix}, oy2 = {-o.y * iy, -o.y * iy}, oz2 = {-o.z * iz, -o.z * iz};
-    const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
-    const uint32_t g_base = octant * (uint32_t)sc.n_nodes * 32u;
     const float2 *l_box_b = reinterpret_cast<const float2 *>(lds_nodes + sc.n_top);
-    const float2 *l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
-
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
-    wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
-    wl.ray_b[lane] = make_float2(d.y, d.z);
-    wl.best[lane] = key0;
-    wave_lds_fence();
 
-    float cull_t = t_max; // the owner's view of its best t
-    int node = valid ? 0 : -1;
-    uint32_t head = 0, count = 0; // wave-uniform
+    // per-ray state of the lane
+    uint32_t my_k = NONE;
+    f32x2 ix2 = {0.0f, 0.0f}, iy2 = ix2, iz2 = ix2, ox2 = ix2, oy2 = ix2, oz2 = ix2;
+    uint32_t g_base = 0;
+    const float2 *l_links = l_box_b;
+    float cull_t = t_max;
+    int node = -1;
+    bool pushed = false;
+    uint32_t last_pos = 0;
+
+    uint32_t next = 0;            // rays of the range handed out so far (wave-uniform)
+    uint32_t head = 0, count = 0; // queue: absolute position of its first entry, entries (wave-uniform)
+    const uint32_t refill = uni((uint32_t)sc.walk_refill);
+    first = uni(first);
+    total = uni(total);
     for (;;) {
-        const bool walking = __ballot(node >= 0) != 0ull;
-        if (!walking && count == 0u) break;
-        if (walking && count < 64u) {
+        // Lanes without work are looked after when enough of them have gathered: their queued leaves are tested at once
+        // (even fewer than 64), which makes their results final, and they take new rays.
+        const uint32_t n_walk = uni((uint32_t)__popcll(__ballot(node >= 0)));
+        const bool starving = uni(next < total && n_walk + refill <= 64u);
+        if (uni(n_walk != 0u && count < 64u && !starving)) {
             // one step of the walk for every lane that has a node; leaves are queued, not tested
             int leaf = -1;
             if (node >= 0) {
@@ -494,14 +509,19 @@ __device__ __forceinline__ TriHit bvh_traverse_deferred(const DevScene &sc, cons
             const unsigned long long m = __ballot(leaf >= 0);
             if (m != 0ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (leaf >= 0) wl.q[(head + count + rank) & 127u] = make_uint2((uint32_t)leaf, lane);
-                count += (uint32_t)__popcll(m);
+                if (leaf >= 0) {
+                    last_pos = head + count + rank;
+                    pushed = true;
+                    wl.q[last_pos & 127u] = make_uint2((uint32_t)leaf, lane);
+                }
+                count = uni(count + (uint32_t)__popcll(m));
             }
             continue;
         }
+        if (uni(count > 0u)) {
         // the exact tests of up to 64 queued leaves, one per lane
         wave_lds_fence();
-        const uint32_t n = min(count, 64u);
+        const uint32_t n = uni(min(count, 64u));
         if (lane < n) {
             const uint2 e = wl.q[(head + lane) & 127u];
             const uint32_t owner = e.y;
@@ -511,9 +531,9 @@ __device__ __forceinline__ TriHit bvh_traverse_deferred(const DevScene &sc, cons
                 const float2 rb = wl.ray_b[owner];
                 const F3 ro = f3(ra.x, ra.y, ra.z), rd = f3(ra.w, rb.x, rb.y);
                 float bound = ANY_HIT ? t_max : float_from_order_key((uint32_t)(seen >> 32));
-                const int first = (int)(e.x >> 3), cnt = (int)(e.x & 7u) + 1;
+                const int tri0 = (int)(e.x >> 3), cnt = (int)(e.x & 7u) + 1;
                 for (int k = 0; k < cnt; k++) {
-                    const uint32_t off = (uint32_t)(first + k) * 48u;
+                    const uint32_t off = (uint32_t)(tri0 + k) * 48u;
                     const u32x4 a = load16(tri_r, off), b = load16(tri_r, off + 16u), c = load16(tri_r, off + 32u);
                     if (COUNT) (*n_tris)++;
                     float t;
@@ -531,24 +551,61 @@ __device__ __forceinline__ TriHit bvh_traverse_deferred(const DevScene &sc, cons
                 }
             }
         }
-        head += n;
-        count -= n;
-        wave_lds_fence();
-        const unsigned long long mine = wl.best[lane];
-        if (ANY_HIT) {
-            if (mine == 0ull) node = -1;
-        } else {
-            cull_t = float_from_order_key((uint32_t)(mine >> 32));
+            head = uni(head + n);
+            count = uni(count - n);
+            wave_lds_fence();
+            const unsigned long long mine = wl.best[lane];
+            if (ANY_HIT) {
+                if (mine == 0ull) node = -1;
+            } else {
+                cull_t = float_from_order_key((uint32_t)(mine >> 32));
+            }
+        }
+        // Retire and refill.  Looked at only here — after a batch of tests, or when nothing is left to do — not at every
+        // step: a lane's result becomes final when its walk is over and the queue has moved past its last leaf.
+        const bool fin = my_k != NONE && node < 0 && (!pushed || (int32_t)(head - last_pos) > 0);
+        const uint32_t n_fin = uni((uint32_t)__popcll(__ballot(fin))), n_idle = uni((uint32_t)__popcll(__ballot(my_k == NONE)));
+        const bool drained = uni(count == 0u && __ballot(node >= 0) == 0ull);
+        if (uni(drained || (next < total && n_fin + n_idle >= refill))) {
+            if (fin) {
+                const unsigned long long r = wl.best[lane];
+                const float4 ra = wl.ray_a[lane];
+                const float2 rb = wl.ray_b[lane];
+                TriHit h{t_max, -1, -1};
+                if (ANY_HIT) {
+                    if (r == 0ull) h.tri = 0;
+                } else if (r != key0) {
+                    h.t = float_from_order_key((uint32_t)(r >> 32));
+                    h.prim = 0x7FFFFFFF - (int)(uint32_t)r;
+                }
+                client.done(my_k, f3(ra.x, ra.y, ra.z), f3(ra.w, rb.x, rb.y), h);
+                my_k = NONE;
+            }
+            const unsigned long long free_m = __ballot(my_k == NONE);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_m, 0u));
+            const uint32_t remaining = uni(total - next);
+            if (my_k == NONE && rank < remaining) {
+                my_k = first + next + rank;
+                F3 o, d;
+                const bool walk = client.fetch(my_k, &o, &d);
+                const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
+                ix2 = f32x2{ix, ix}; iy2 = f32x2{iy, iy}; iz2 = f32x2{iz, iz};
+                ox2 = f32x2{-o.x * ix, -o.x * ix}; oy2 = f32x2{-o.y * iy, -o.y * iy}; oz2 = f32x2{-o.z * iz, -o.z * iz};
+                const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
+                g_base = octant * (uint32_t)sc.n_nodes * 32u;
+                l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
+                wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+                wl.ray_b[lane] = make_float2(d.y, d.z);
+                wl.best[lane] = (ANY_HIT && !walk) ? 0ull : key0;
+                cull_t = t_max;
+                node = (walk && sc.n_nodes > 0) ? 0 : -1;
+                pushed = false;
+            }
+            next = uni(next + min((uint32_t)__popcll(free_m), remaining));
+            wave_lds_fence();
+            if (uni(drained && __ballot(my_k != NONE) == 0ull)) break; // nothing in flight, nothing left to hand out
         }
     }
-    const unsigned long long fin = wl.best[lane];
-    if (ANY_HIT) {
-        if (fin == 0ull) { best.tri = 0; best.prim = 0; }
-    } else if (fin != key0) {
-        best.t = float_from_order_key((uint32_t)(fin >> 32));
-        best.prim = 0x7FFFFFFF - (int)(uint32_t)fin;
-    }
-    return best;
 }
 
 // The loose triangles, one after the other, for a ray that misses the boxes of all big meshes.  The loop is the same for
@@ -593,48 +650,6 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
     *t_out = closest;
     *code_out = code;
     *prim_out = prim;
-}
-
-// the same with the wave-cooperative walk: every lane of the wave must call it
-template <bool COUNT, bool USE_LDS>
-__device__ __forceinline__ void world_hit_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
-                                                   float t_max, float *t_out, int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
-    const TriHit th = bvh_traverse_deferred<false, COUNT, USE_LDS>(sc, lds_nodes, wl, valid, o, d, t_min, t_max, n_nodes, n_tris);
-    float closest = th.t;
-    int code = HIT_NONE, prim = th.prim;
-    if (!valid) return;
-    if (th.prim >= 0) code = hit_code(HIT_KIND_TRI, sc.tri_of_prim[th.prim]);
-    for (int i = 0; i < sc.n_sph; i++) {
-        float t;
-        if (sph_hit(sc.sph[i], o, d, t_min, closest, &t)) { closest = t; code = hit_code(HIT_KIND_SPH, i); prim = sc.sph_info[i].y; }
-    }
-    for (int i = 0; i < sc.n_cyl; i++) {
-        float t;
-        int kind;
-        if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, closest, &t, &kind)) { closest = t; code = hit_code(kind, i); prim = sc.cyl_info[i].y; }
-    }
-    *t_out = closest;
-    *code_out = code;
-    *prim_out = prim;
-}
-
-template <bool COUNT, bool USE_LDS>
-__device__ __forceinline__ bool world_occluded_deferred(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, bool valid, F3 o, F3 d, float t_min,
-                                                        float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
-    bool occ = false;
-    if (valid) {
-        for (int i = 0; i < sc.n_sph && !occ; i++) {
-            float t;
-            occ = sph_hit(sc.sph[i], o, d, t_min, t_max, &t);
-        }
-        for (int i = 0; i < sc.n_cyl && !occ; i++) {
-            float t;
-            int kind;
-            occ = cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind);
-        }
-    }
-    const TriHit th = bvh_traverse_deferred<true, COUNT, USE_LDS>(sc, lds_nodes, wl, valid && !occ, o, d, t_min, t_max, n_nodes, n_tris);
-    return occ || th.tri >= 0;
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)

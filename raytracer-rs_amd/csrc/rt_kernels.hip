@@ -282,14 +282,61 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, C
 }
 
 // ---- k_extend -------------------------------------------------------------------------------------------------------
-// grid (blocks, RT_NSEG): workgroup (bx, s) handles nodes [bx*256, bx*256+256) of segment s.
-// hit record: (t_obj, object code)
+// One-dimensional grid, heavy segments first (decode_block).  Light segments: workgroup (bx, s) handles nodes
+// [bx*256, bx*256+256) of segment s, one per thread.  Heavy segments (when sc.deferred): every wave owns `heavy_span`
+// consecutive nodes and walks them with walk_range.  hit record: (t_obj, object code)
+struct ExtendClient {
+    const DevScene &sc;
+    const RenderConst &rc;
+    const NodeQueue &in;
+    float2 *hit;
+    uint32_t base; // first slot of the segment
+    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d) const {
+        const float4 a = in.a[base + k], b = in.b[base + k];
+        *o = f3(a.x, a.y, a.z);
+        *d = f3(a.w, b.x, b.y);
+        return true;
+    }
+    // world.objects.hit (hitable.rs:35-62) once the triangles are done: spheres and cylinders need t < closest
+    __device__ __forceinline__ void done(uint32_t k, F3 o, F3 d, const TriHit &h) const {
+        float closest = h.t;
+        int code = h.prim >= 0 ? hit_code(HIT_KIND_TRI, sc.tri_of_prim[h.prim]) : HIT_NONE;
+        for (int i = 0; i < sc.n_sph; i++) {
+            float t;
+            if (sph_hit(sc.sph[i], o, d, rc.t_min, closest, &t)) { closest = t; code = hit_code(HIT_KIND_SPH, i); }
+        }
+        for (int i = 0; i < sc.n_cyl; i++) {
+            float t;
+            int kind;
+            if (cyl_hit(sc.cyl + 5 * i, o, d, rc.t_min, closest, &t, &kind)) { closest = t; code = hit_code(kind, i); }
+        }
+        hit[base + k] = make_float2(closest, __int_as_float(code));
+    }
+};
+
 template <bool COUNT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, float2 *hit, uint32_t seg_capacity,
-                                                  uint32_t heavy_blocks) {
+                                                  uint32_t heavy_blocks, uint32_t heavy_span) {
     extern __shared__ float4 lds_nodes[];
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    if (seg >= RT_NSEG_HALF && sc.deferred) {
+        const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
+        const uint32_t wg_first = bx * (BLOCK / 64) * heavy_span;
+        if (wg_first >= n_seg) return;
+        if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+        const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
+        const uint32_t total = first < n_seg ? min(heavy_span, n_seg - first) : 0u;
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
+        ExtendClient client{sc, rc, in, hit, seg * seg_capacity};
+        uint32_t nn = 0, nt = 0;
+        walk_range<false, COUNT, USE_LDS>(sc, lds_nodes, areas[wave], client, first, total, rc.t_min, rc.t_max, &nn, &nt);
+        if (COUNT) {
+            atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
+            atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+        }
+        return;
+    }
     const uint32_t il = bx * BLOCK + threadIdx.x;
     const uint32_t i = seg * seg_capacity + il;
     // The ray is fetched before the segment's fill count is known (a wave lives about 2 us, and waiting for the count
@@ -301,18 +348,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     if (bx * BLOCK >= n_seg) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0; // light rays scan the few triangles outside the big meshes
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
+    if (il >= n_seg) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
-    float t_obj = 0.0f;
-    int code = HIT_NONE, prim = -1;
+    float t_obj;
+    int code, prim;
     uint32_t nn = 0, nt = 0;
-    if (seg >= RT_NSEG_HALF && sc.deferred) {
-        // heavy rays: the whole wave walks together and tests queued leaves 64 at a time (lanes without a ray take part)
-        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
-        world_hit_deferred<COUNT, USE_LDS>(sc, lds_nodes, areas[threadIdx.x >> 6], il < n_seg, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
-        if (il >= n_seg) return;
-    } else if (il >= n_seg) return;
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
-    else if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
     hit[i] = make_float2(t_obj, __int_as_float(code));
@@ -673,12 +715,61 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
 }
 
 // ---- k_shadow --------------------------------------------------------------------------------------------------------
+struct ShadowClient {
+    const DevScene &sc;
+    const RenderConst &rc;
+    const ShadowQueue &sh;
+    float *planes;
+    uint32_t n_pixels;
+    uint32_t base; // first slot of the segment
+    // world.hit(r, T_MIN, 1 - T_MIN): spheres and cylinders first; false = already occluded, no walk
+    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d) const {
+        const float4 a = sh.a[base + k], b = sh.b[base + k];
+        *o = f3(a.x, a.y, a.z);
+        *d = f3(a.w, b.x, b.y);
+        bool occ = false;
+        for (int i = 0; i < sc.n_sph && !occ; i++) {
+            float t;
+            occ = sph_hit(sc.sph[i], *o, *d, rc.t_min, 1.0f - rc.t_min, &t);
+        }
+        for (int i = 0; i < sc.n_cyl && !occ; i++) {
+            float t;
+            int kind;
+            occ = cyl_hit(sc.cyl + 5 * i, *o, *d, rc.t_min, 1.0f - rc.t_min, &t, &kind);
+        }
+        return !occ;
+    }
+    __device__ __forceinline__ void done(uint32_t k, F3, F3, const TriHit &h) const {
+        if (h.tri >= 0) return; // occluded
+        const float4 b = sh.b[base + k];
+        const float2 c = sh.c[base + k];
+        add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
+    }
+};
+
 template <bool COUNT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
-                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
+                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks, uint32_t heavy_span) {
     extern __shared__ float4 lds_nodes[];
     uint32_t seg, bx;
     decode_block(blockIdx.x, heavy_blocks, &seg, &bx);
+    if (seg >= RT_NSEG_HALF && sc.deferred) {
+        const uint32_t n = min(ctl->seg_shadow_cur[seg], shadow_seg_capacity);
+        const uint32_t wg_first = bx * (BLOCK / 64) * heavy_span;
+        if (wg_first >= n) return;
+        if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
+        const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
+        const uint32_t total = first < n ? min(heavy_span, n - first) : 0u;
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
+        ShadowClient client{sc, rc, sh, planes, n_pixels, seg * shadow_seg_capacity};
+        uint32_t nn = 0, nt = 0;
+        walk_range<true, COUNT, USE_LDS>(sc, lds_nodes, areas[wave], client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+        if (COUNT) {
+            atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
+            atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+        }
+        return;
+    }
     const uint32_t il = bx * BLOCK + threadIdx.x;
     // fetched before the fill count is known, like the ray of k_extend
     const uint32_t i = seg * shadow_seg_capacity + min(il, shadow_seg_capacity - 1u);
@@ -688,18 +779,11 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     if (bx * BLOCK >= n) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0;
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
+    if (il >= n) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     uint32_t nn = 0, nt = 0;
-    bool occ;
-    if (seg >= RT_NSEG_HALF && sc.deferred) {
-        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
-        occ = world_occluded_deferred<COUNT, USE_LDS>(sc, lds_nodes, areas[threadIdx.x >> 6], il < n, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
-        if (il >= n) return;
-    } else {
-        if (il >= n) return;
-        occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
-                    : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
-    }
+    const bool occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
+                           : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
@@ -841,20 +925,33 @@ void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &
     hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, sc, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
 }
 
-static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads, uint32_t *heavy_blocks) {
-    *heavy_blocks = nblocks(heavy_threads);
+static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads, uint32_t *heavy_blocks, uint32_t heavy_span = 64) {
+    const uint32_t per_block = (BLOCK / 64) * heavy_span; // heavy rays one workgroup takes
+    *heavy_blocks = (heavy_threads + per_block - 1) / per_block;
     return RT_NSEG_HALF * (*heavy_blocks + nblocks(light_threads));
+}
+
+// Rays per wave of the heavy segments (walk_range): longer ranges keep the lanes busier, shorter ones give more waves.
+// Enough waves to fill the chip several times over come first.
+static inline uint32_t heavy_span_for(const DevScene &sc, uint32_t heavy_threads, bool count) {
+    if (!sc.deferred || count) return 64u;
+    const uint32_t waves_wanted = 256u * 4u * 8u; // 8 per SIMD
+    uint32_t k = (uint32_t)(((unsigned long long)heavy_threads * RT_NSEG_HALF / 64u) / waves_wanted);
+    const uint32_t k_max = (uint32_t)sc.walk_span;
+    k = k < 1u ? 1u : (k > k_max ? k_max : k);
+    return 64u * k;
 }
 
 void launch_extend(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, float2 *hit, uint32_t light_threads,
                    uint32_t heavy_threads, bool count) {
     uint32_t hb;
-    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    const uint32_t span = heavy_span_for(sc, heavy_threads, count);
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb, span);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-    else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
-    else hipLaunchKernelGGL((k_extend<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb);
+    if (count) hipLaunchKernelGGL((k_extend<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb, span);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_extend<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb, span);
+    else hipLaunchKernelGGL((k_extend<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, in, hit, cfg.seg_capacity, hb, span);
 }
 
 void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
@@ -874,12 +971,13 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,
                    uint32_t light_threads, uint32_t heavy_threads, bool count) {
     uint32_t hb;
-    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
+    const uint32_t span = heavy_span_for(sc, heavy_threads, count);
+    const uint32_t grid = class_grid(light_threads, heavy_threads, &hb, span);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-    else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
-    else hipLaunchKernelGGL((k_shadow<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb);
+    if (count) hipLaunchKernelGGL((k_shadow<true, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb, span);
+    else if (sc.n_top > 0) hipLaunchKernelGGL((k_shadow<false, true>), g, b, lds_bytes(sc, true), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb, span);
+    else hipLaunchKernelGGL((k_shadow<false, false>), g, b, lds_bytes(sc, false), cfg.stream, sc, rc, ctl, sh, planes, n_pixels, cfg.shadow_seg_capacity, hb, span);
 }
 
 void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes,

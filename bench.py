@@ -206,7 +206,10 @@ def main() -> int:
         shadow = sum(s.rays_shadow for s in stats)
         cams = sum(s.camera_samples for s in stats)
         children_per_node = (closest - cams) / max(1, closest)
-        shadow_per_node = shadow / max(1, closest)
+        inline = sum(s.rays_shadow_inline for s in stats)  # occlusion queries k_shade answered itself: no queue traffic
+        queued = shadow - inline
+        shadow_per_node = queued / max(1, closest)
+        inline_per_node = inline / max(1, closest)
         stage_ms = {k: sum(getattr(s, "ms_" + k) for s in stats) / steps for k in ("extend", "shade", "shadow", "raygen")}
         # mean BVH work per ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
         nodes_per_ray = tris_per_ray = 0.0
@@ -223,8 +226,9 @@ def main() -> int:
         cache_bytes_per_ray = 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
         per_unit = {  # kernel: (units over the timed steps, algorithmic HBM bytes per unit, launches, total ms)
             "k_extend": (closest, 32 + 8, sum(s.launches_extend for s in stats), sum(s.ms_extend for s in stats)),
-            "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node, sum(s.launches_shade for s in stats), sum(s.ms_shade for s in stats)),
-            "k_shadow": (shadow, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
+            "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node + 12 * inline_per_node, sum(s.launches_shade for s in stats),
+                        sum(s.ms_shade for s in stats)),
+            "k_shadow": (queued, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
         }
         # HBM traffic from the PMC counters is not collected by this run: it comes from the committed counter passes of
         # this same command, and only when they were taken on a library built from the sources in this tree

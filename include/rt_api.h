@@ -140,6 +140,7 @@ typedef struct rt_stats {
     double ms_total;         /* wall time of the call, device work complete */
     double ms_extend, ms_shade, ms_shadow, ms_raygen; /* RT_FLAG_TIMING: summed HIP-event durations */
     uint64_t device_bytes;   /* device memory the context holds for queues and planes after this call */
+    uint64_t rays_shadow_inline; /* of rays_shadow: answered by the shading kernel itself, never written to the shadow queue */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -225,7 +226,9 @@ void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp)
  * triangles (9 floats each; primitive id = position in the list) and copies it out.  Takes the place of
  * BVHTree::build_tree (src/mesh.rs:225-261).  Layout: `ordered` != 0 gives 8 node arrays, one per sign octant of the
  * ray direction (bit a of the array index set = component a negative), else 1; each array has *n_nodes nodes of 8
- * floats: xmin, xmax, ymin, ymax, zmin, zmax, link, miss (the last two are int32 bit patterns).  link >= 0: node to
+ * floats: xmin, xmax, ymin, ymax, zmin, zmax, link, miss (the last two are int32 bit patterns); with 8 arrays the pair
+ * of an axis is stored as (max, min) in the arrays of the octants whose direction is negative along that axis, i.e.
+ * always (plane the octant's rays enter through, plane they leave through).  link >= 0: node to
  * continue with when the box is hit; link < 0: leaf with triangles [first, first + count), ~link = first * 8 + count - 1.
  * miss: node to continue with when the box is missed or the leaf is done, -1 = walk finished.  Triangles are written
  * in leaf order, 12 floats each: v0.xyz, primitive id (int32 bits), v1 - v0, material (int32 bits, 0 here), v2 - v0, 0.

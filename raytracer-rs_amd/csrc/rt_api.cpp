@@ -797,6 +797,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         st.camera_samples = c.cam_samples;
         st.rays_closest = c.rays_closest;
         st.rays_shadow = c.rays_shadow;
+        st.rays_shadow_inline = c.rays_shadow_inline;
         st.nodes_visited = c.nodes;
         st.tris_tested = c.tris;
         if ((p->flags & RT_FLAG_COUNT_WORK) && getenv("RT_DUMP_HIST")) { // development aid: distribution of closest-hit walk lengths

@@ -283,9 +283,13 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             stack.pop_back();
             const TmpNode &nd = b.nodes[it.id];
             float *dst = base + 8 * (size_t)index[it.id];
-            dst[0] = nd.box.mn[0]; dst[1] = nd.box.mx[0];
-            dst[2] = nd.box.mn[1]; dst[3] = nd.box.mx[1];
-            dst[4] = nd.box.mn[2]; dst[5] = nd.box.mx[2];
+            // each pair is (plane the rays of this octant enter through, plane they leave through): (min, max) along an
+            // axis whose direction component is positive, (max, min) along a negative one
+            for (int a = 0; a < 3; a++) {
+                const bool neg = ordered && ((k >> a) & 1);
+                dst[2 * a] = neg ? nd.box.mx[a] : nd.box.mn[a];
+                dst[2 * a + 1] = neg ? nd.box.mn[a] : nd.box.mx[a];
+            }
             dst[7] = int_bits(it.next);
             if (!kids[it.id].empty()) {
                 const std::vector<int> v = sorted_kids(it.id, order);

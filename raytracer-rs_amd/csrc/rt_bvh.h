@@ -18,6 +18,7 @@ namespace rtd {
 
 struct BvhBuild {
     std::vector<float> nodes; // n_orders arrays of n_nodes nodes, 8 floats each: xmin, xmax, ymin, ymax, zmin, zmax, link, miss (int bits);
+                              // with 8 orders the pair of an axis is (max, min) in the arrays of octants whose direction is negative along it;
                               // link >= 0: first child, link < 0: ~(first_triangle * 8 + count - 1); miss: next node, -1 = walk finished
     std::vector<float> tris;  // 12 floats per triangle in leaf order: v0.xyz, prim, e1.xyz, mat, e2.xyz, 0
     int n_nodes = 0;

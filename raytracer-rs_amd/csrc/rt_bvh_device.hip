@@ -203,9 +203,11 @@ __global__ __launch_bounds__(BB) void k_bvh_thread(int n, int n_orders, const in
         cur = p;
     }
     const Box6 b = nbox[idx];
+    // (entry plane, exit plane) per axis for the rays of this octant: (max, min) where the direction is negative
+    const bool nx = n_orders == 8 && (k & 1), ny = n_orders == 8 && (k & 2), nz = n_orders == 8 && (k & 4);
     float4 *dst = nodes + 2 * ((size_t)k * (size_t)nn + (size_t)idx);
-    dst[0] = make_float4(b.mn[0], b.mx[0], b.mn[1], b.mx[1]);
-    dst[1] = make_float4(b.mn[2], b.mx[2], __int_as_float(link), __int_as_float(miss));
+    dst[0] = make_float4(nx ? b.mx[0] : b.mn[0], nx ? b.mn[0] : b.mx[0], ny ? b.mx[1] : b.mn[1], ny ? b.mn[1] : b.mx[1]);
+    dst[1] = make_float4(nz ? b.mx[2] : b.mn[2], nz ? b.mn[2] : b.mx[2], __int_as_float(link), __int_as_float(miss));
 }
 
 __global__ void k_bvh_init_bounds(int *bounds) {

@@ -451,21 +451,20 @@ __device__ __forceinline__ void wave_lds_fence() {
 //                           void done(uint32_t k, F3 o, F3 d, const TriHit &h)   closest hit: h.prim (-1 = none), h.t;
 //                                                                                 occlusion query: h.tri >= 0 = occluded
 // Every lane of the wave must call walk_range; `wl` is the calling wave's own area.
-template <bool ANY_HIT, bool COUNT, bool USE_LDS, class Client>
-__device__ __forceinline__ void walk_range(const DevScene &sc, const float4 *lds_nodes, WaveWalkLds &wl, Client &client, uint32_t first, uint32_t total,
+template <bool ANY_HIT, bool COUNT, class Client>
+__device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, Client &client, uint32_t first, uint32_t total,
                                            float t_min, float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t NONE = 0xFFFFFFFFu;
     const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 32u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
-    const float2 *l_box_b = reinterpret_cast<const float2 *>(lds_nodes + sc.n_top);
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
+    const bool presorted = sc.n_orders == 8;
 
     // per-ray state of the lane
     uint32_t my_k = NONE;
     f32x2 ix2 = {0.0f, 0.0f}, iy2 = ix2, iz2 = ix2, ox2 = ix2, oy2 = ix2, oz2 = ix2;
     uint32_t g_base = 0;
-    const float2 *l_links = l_box_b;
     float cull_t = t_max;
     int node = -1;
     bool pushed = false;
@@ -485,22 +484,20 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, const float4 *lds
             // one step of the walk for every lane that has a node; leaves are queued, not tested
             int leaf = -1;
             if (node >= 0) {
-                u32x4 na, nb;
-                if (USE_LDS && node < sc.n_top) {
-                    const float4 fa = lds_nodes[node];
-                    const float2 fb = l_box_b[node], fl = l_links[node];
-                    na = u32x4{__float_as_uint(fa.x), __float_as_uint(fa.y), __float_as_uint(fa.z), __float_as_uint(fa.w)};
-                    nb = u32x4{__float_as_uint(fb.x), __float_as_uint(fb.y), __float_as_uint(fl.x), __float_as_uint(fl.y)};
-                } else {
-                    na = load16(node_r, g_base + (uint32_t)node * 32u);
-                    nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);
-                }
+                const u32x4 na = load16(node_r, g_base + (uint32_t)node * 32u);
+                const u32x4 nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);
                 if (COUNT) (*n_nodes)++;
                 const f32x2 tx = __builtin_elementwise_fma(f32x2{u2f(na.x), u2f(na.y)}, ix2, ox2);
                 const f32x2 ty = __builtin_elementwise_fma(f32x2{u2f(na.z), u2f(na.w)}, iy2, oy2);
                 const f32x2 tz = __builtin_elementwise_fma(f32x2{u2f(nb.x), u2f(nb.y)}, iz2, oz2);
-                const float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
-                const float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
+                float tn, tf;
+                if (presorted) { // the node array of the ray's octant holds (entry plane, exit plane) per axis
+                    tn = fmaxf(__builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x), t_min);
+                    tf = fminf(__builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y), cull_t);
+                } else {
+                    tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
+                    tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
+                }
                 const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
                 const int link = (int)nb.z, miss = (int)nb.w;
                 leaf = (inside && link < 0) ? ~link : -1;
@@ -591,9 +588,10 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, const float4 *lds
                 const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
                 ix2 = f32x2{ix, ix}; iy2 = f32x2{iy, iy}; iz2 = f32x2{iz, iz};
                 ox2 = f32x2{-o.x * ix, -o.x * ix}; oy2 = f32x2{-o.y * iy, -o.y * iy}; oz2 = f32x2{-o.z * iz, -o.z * iz};
-                const uint32_t octant = sc.n_orders == 8 ? ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u)) : 0u;
+                // the octant is taken from the SIGN BITS (a component of -0 has a reciprocal of -inf): it decides which of a
+                // node's two planes per axis is the entry plane, and must agree with the sign of the reciprocal
+                const uint32_t octant = presorted ? ((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2)) : 0u;
                 g_base = octant * (uint32_t)sc.n_nodes * 32u;
-                l_links = l_box_b + sc.n_top + octant * (uint32_t)sc.n_top;
                 wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
                 wl.ray_b[lane] = make_float2(d.y, d.z);
                 wl.best[lane] = (ANY_HIT && !walk) ? 0ull : key0;

@@ -56,6 +56,7 @@ struct CtlHead {
     unsigned long long cursor; // next camera candidate not yet generated
     unsigned long long total;  // all camera candidates of this render call
     unsigned long long rays_closest, rays_shadow, cam_samples, nodes, tris;
+    unsigned long long rays_shadow_inline; // of rays_shadow: answered inside k_shade
     // work-counting launches only: closest-hit rays / waves by floor(log2(visited nodes)) + 1 (bucket 0 = none), and the
     // sum over waves of the largest count among their lanes (the walk length the wave actually pays for)
     unsigned long long hist_ray[16], hist_wave[16], wave_steps, wave_tri_iters;

@@ -203,7 +203,10 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     // close the iteration that just ran: it extended prev_in nodes, n_alive of which were carried in, the rest new camera rays
     h.rays_closest += prev_in;
     h.rays_shadow += prev_shadow;
-    for (int k = 0; k < RT_NSEG_HALF; k++) h.rays_shadow += s_inl[k];
+    for (int k = 0; k < RT_NSEG_HALF; k++) {
+        h.rays_shadow += s_inl[k];
+        h.rays_shadow_inline += s_inl[k];
+    }
     h.cam_samples += prev_in - h.n_alive;
     unsigned long long remaining = h.total - h.cursor;
     uint32_t n_new = 0;
@@ -324,13 +327,12 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
         const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
         const uint32_t wg_first = bx * (BLOCK / 64) * heavy_span;
         if (wg_first >= n_seg) return;
-        if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
         const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
         const uint32_t total = first < n_seg ? min(heavy_span, n_seg - first) : 0u;
         WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
         ExtendClient client{sc, rc, in, hit, seg * seg_capacity};
         uint32_t nn = 0, nt = 0;
-        walk_range<false, COUNT, USE_LDS>(sc, lds_nodes, areas[wave], client, first, total, rc.t_min, rc.t_max, &nn, &nt);
+        walk_range<false, COUNT>(sc, areas[wave], client, first, total, rc.t_min, rc.t_max, &nn, &nt);
         if (COUNT) {
             atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
             atomicAdd(&ctl->h.tris, (unsigned long long)nt);
@@ -757,13 +759,12 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
         const uint32_t n = min(ctl->seg_shadow_cur[seg], shadow_seg_capacity);
         const uint32_t wg_first = bx * (BLOCK / 64) * heavy_span;
         if (wg_first >= n) return;
-        if (USE_LDS) fill_top_cache<BLOCK>(sc, lds_nodes);
         const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
         const uint32_t total = first < n ? min(heavy_span, n - first) : 0u;
         WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
         ShadowClient client{sc, rc, sh, planes, n_pixels, seg * shadow_seg_capacity};
         uint32_t nn = 0, nt = 0;
-        walk_range<true, COUNT, USE_LDS>(sc, lds_nodes, areas[wave], client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+        walk_range<true, COUNT>(sc, areas[wave], client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
         if (COUNT) {
             atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
             atomicAdd(&ctl->h.tris, (unsigned long long)nt);

@@ -96,9 +96,17 @@ def test_structure(rt, n, ordered):
     assert np.array_equal(tris[:, 0:3], tri_v[prim, 0:3])
     assert np.array_equal(tris[:, 4:7], tri_v[prim, 3:6] - tri_v[prim, 0:3])
     assert np.array_equal(tris[:, 8:11], tri_v[prim, 6:9] - tri_v[prim, 0:3])
-    # the boxes are the same in every order
+    # the boxes are the same in every order; the array of octant k stores each axis' pair as (entry plane, exit plane)
+    # for its rays: (max, min) along the axes whose direction component is negative (bit a of k)
     for k in range(1, nodes.shape[0]):
-        assert np.array_equal(nodes[k, :, :6], nodes[0, :, :6])
+        for a in range(3):
+            pair = nodes[k, :, 2 * a:2 * a + 2]
+            want = nodes[0, :, 2 * a:2 * a + 2][:, ::-1] if (k >> a) & 1 else nodes[0, :, 2 * a:2 * a + 2]
+            assert np.array_equal(pair, want)
+    nodes = nodes.copy()
+    for k in range(nodes.shape[0]):  # back to (min, max) for the checks below
+        for a in range(3):
+            nodes[k, :, 2 * a:2 * a + 2] = np.sort(nodes[k, :, 2 * a:2 * a + 2], axis=1)
     for k in range(nodes.shape[0]):
         link, miss = links(nodes[k])
         # following link at inner nodes and miss at leaves visits every node exactly once, every triangle exactly once

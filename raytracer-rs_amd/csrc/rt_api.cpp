@@ -93,6 +93,7 @@ struct rt_context {
 struct rt_scene {
     rt_context *ctx = nullptr;
     DevBuf<float4> nodes, tris, sph, loose;
+    DevBuf<uint4> cnodes;
     DevBuf<int2> sph_info, cyl_info;
     DevBuf<int32_t> tri_of_prim;
     DevBuf<float> cyl, ltris;
@@ -510,9 +511,13 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     }
     if (on_device) {
         hipError_t e = s->nodes.ensure(2 * (size_t)bvh.n_nodes * (size_t)bvh.n_orders);
+        if (e == hipSuccess) e = s->cnodes.ensure((size_t)bvh.n_nodes * (size_t)bvh.n_orders);
         if (e == hipSuccess) e = s->tris.ensure(3 * (size_t)d->n_tri);
         std::vector<uint32_t> order((size_t)d->n_tri);
-        if (e == hipSuccess) e = build_bvh_device(ctx->stream, d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, ordered, s->nodes.p, s->tris.p, order.data());
+        float qp[6] = {0, 0, 0, 1, 1, 1};
+        if (e == hipSuccess)
+            e = build_bvh_device(ctx->stream, d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp);
+        for (int a = 0; a < 3; a++) { bvh.q_lo[a] = qp[a]; bvh.q_scale[a] = qp[3 + a]; }
         if (e != hipSuccess) return cleanup_fail(e, "BVH build on the device");
         // host copy of the triangle records, in the device's leaf order: the loose list and the primitive -> record table below read it
         bvh.tris.resize(12 * (size_t)d->n_tri);
@@ -530,8 +535,11 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         }
     } else {
         UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
+        UP(s->cnodes, bvh.cnodes.data(), bvh.cnodes.size() / 4, uint4);
         UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
     }
+    for (int a = 0; a < 3; a++) { s->dev.q_lo[a] = bvh.q_lo[a]; s->dev.q_scale[a] = bvh.q_scale[a]; }
+    s->dev.cnodes = s->cnodes.p;
     s->info.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     s->info.bvh_on_device = on_device ? 1 : 0;
     s->info.n_nodes = bvh.n_nodes; s->info.n_orders = bvh.n_orders; s->info.n_top = bvh.n_top; s->info.n_triangles = d->n_tri;
@@ -551,6 +559,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     s->dev.cyl = s->cyl.p; s->dev.cyl_info = s->cyl_info.p; s->dev.mats = s->mats.p; s->dev.lights = s->lights.p; s->dev.ltris = s->ltris.p;
     s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_orders = bvh.n_orders; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
     s->dev.n_light = d->n_light;
+    s->dev.n_mat = d->n_mat; s->dev.n_light_tri = d->n_light_tri;
     // Boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box),
     // each the union of its triangles' boxes padded as the BVH pads them: a ray that misses all of them cannot hit a
     // triangle of a big mesh.  Such rays are kept apart in the queues, and when the triangles outside the big meshes
@@ -638,7 +647,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
-    s->nodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
+    s->nodes.release(); s->cnodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
     s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
     delete s;
     return RT_OK;

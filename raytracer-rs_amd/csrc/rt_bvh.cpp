@@ -301,6 +301,56 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
         }
     }
 
+    // ---- the compact copy: per order, nodes in that order's depth-first sequence
+    {
+        const Box &rb = b.nodes[root].box;
+        for (int a = 0; a < 3; a++) {
+            out->q_lo[a] = rb.mn[a];
+            const float ext = rb.mx[a] - rb.mn[a];
+            out->q_scale[a] = ext > 0.0f ? ext / 65535.0f : 1.0f;
+        }
+        auto quant = [&](float v, int a, bool up) {
+            double q = ((double)v - (double)out->q_lo[a]) / (double)out->q_scale[a];
+            long long i = up ? (long long)std::ceil(q) + 1 : (long long)std::floor(q) - 1; // one step outwards: the kernel's float evaluation of q_lo + q * q_scale rounds
+            return (uint32_t)std::min<long long>(65535, std::max<long long>(0, i));
+        };
+        out->cnodes.assign(4 * (size_t)nn * (size_t)out->n_orders, 0u);
+        std::vector<int> dfs; // nodes of the current order in visiting sequence
+        std::vector<int> subtree(b.nodes.size(), 0);
+        for (int k = 0; k < out->n_orders; k++) {
+            const int order = ordered ? k : 8;
+            uint32_t *base = &out->cnodes[4 * (size_t)nn * (size_t)k];
+            // iterative pre-order walk; subtree sizes from a post-order pass over the same sequence
+            dfs.clear();
+            std::vector<int> st{root};
+            while (!st.empty()) {
+                const int id = st.back();
+                st.pop_back();
+                dfs.push_back(id);
+                if (!kids[id].empty()) {
+                    const std::vector<int> v = sorted_kids(id, order);
+                    for (size_t i = v.size(); i-- > 0;) st.push_back(v[i]);
+                }
+            }
+            for (size_t i = dfs.size(); i-- > 0;) {
+                int sz = 1;
+                for (int c : kids[dfs[i]]) sz += subtree[c];
+                subtree[dfs[i]] = sz;
+            }
+            for (size_t i = 0; i < dfs.size(); i++) {
+                const TmpNode &nd = b.nodes[dfs[i]];
+                uint32_t *dst = base + 4 * i;
+                for (int a = 0; a < 3; a++) {
+                    const bool neg = ordered && ((k >> a) & 1);
+                    const uint32_t lo = quant(nd.box.mn[a], a, false), hi = quant(nd.box.mx[a], a, true);
+                    dst[a] = neg ? (hi | (lo << 16)) : (lo | (hi << 16));
+                }
+                if (kids[dfs[i]].empty()) dst[3] = 0x80000000u | (uint32_t)(nd.first * 8 + (nd.count - 1));
+                else dst[3] = (uint32_t)(i + (size_t)subtree[dfs[i]]);
+            }
+        }
+    }
+
     out->tris.resize(12 * (size_t)n_tri);
     for (int i = 0; i < n_tri; i++) {
         int t = b.order[i];

@@ -21,6 +21,14 @@ struct BvhBuild {
                               // with 8 orders the pair of an axis is (max, min) in the arrays of octants whose direction is negative along it;
                               // link >= 0: first child, link < 0: ~(first_triangle * 8 + count - 1); miss: next node, -1 = walk finished
     std::vector<float> tris;  // 12 floats per triangle in leaf order: v0.xyz, prim, e1.xyz, mat, e2.xyz, 0
+    // The same tree once more in 16-byte nodes, for the walk that is bound by the number of cache lines it touches, not by
+    // arithmetic: n_orders arrays of n_nodes nodes in the DEPTH-FIRST ORDER OF THAT OCTANT's visiting order, so a node's
+    // first child is the next node and only the index to continue with after a miss is stored.  Four words:
+    // x, y, z = entry plane | exit plane << 16, quantised to 16 bits over the root box (q_lo + q * q_scale; rounded
+    // outwards by one step); w = inner node: index to go on with when the box is missed (n_nodes = walk finished);
+    // leaf: 0x80000000 | first_triangle * 8 + count - 1 (a leaf is always followed by the next node).
+    std::vector<uint32_t> cnodes;
+    float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
     int n_nodes = 0;
     int n_orders = 1;         // 8: one node array per direction octant (bit a set = component a negative); 1: direction-independent order
     int n_top = 0;            // nodes [0, n_top) are the part of the tree rays meet most often (largest boxes, parents before children)

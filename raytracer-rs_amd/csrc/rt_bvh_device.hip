@@ -109,7 +109,7 @@ __device__ __forceinline__ int common_prefix(const unsigned long long *keys, int
 }
 
 // one thread per inner node: its range of sorted keys and where the range splits (highest differing bit)
-__global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *keys, int n, int2 *children, int *parent) {
+__global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *keys, int n, int2 *children, int *parent, int2 *range) {
     const int i = blockIdx.x * BB + threadIdx.x;
     if (i >= n - 1) return;
     const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *
     const int left = min(i, j) == gamma ? (n - 1) + gamma : gamma;
     const int right = max(i, j) == gamma + 1 ? (n - 1) + gamma + 1 : gamma + 1;
     children[i] = make_int2(left, right);
+    range[i] = make_int2(min(i, j), max(i, j)); // leaves (sorted positions) under this node
     parent[left] = i;
     parent[right] = i;
     if (i == 0) parent[0] = -1;
@@ -210,6 +211,41 @@ __global__ __launch_bounds__(BB) void k_bvh_thread(int n, int n_orders, const in
     dst[1] = make_float4(nz ? b.mx[2] : b.mn[2], nz ? b.mn[2] : b.mx[2], __int_as_float(link), __int_as_float(miss));
 }
 
+// The 16-byte copy of the tree (layout: rt_bvh.h): per order, node `idx` goes to its position in that order's depth-first
+// sequence — one more than its parent's position, plus the whole subtree of the sibling if that one is visited first —
+// with its planes quantised to 16 bits over the root box, one step outwards, and the position to go on with after a miss
+// (its own position + the size of its subtree).  An inner node over leaves [a, b] has 2 (b - a) + 1 nodes below and including it.
+__global__ __launch_bounds__(BB) void k_bvh_compact(int n, int n_orders, const int2 *children, const int *parent, const unsigned char *swap_mask,
+                                                    const int2 *range, const Box6 *nbox, uint4 *cnodes, float *q_params) {
+    const int nn = 2 * n - 1;
+    const long long g = (long long)blockIdx.x * BB + threadIdx.x;
+    if (g >= (long long)nn * n_orders) return;
+    const int k = (int)(g / nn), idx = (int)(g - (long long)k * nn);
+    const int ko = n_orders == 8 ? k : 0;
+    auto size_of = [&](int c) { return c >= n - 1 ? 1 : 2 * (range[c].y - range[c].x) + 1; };
+    int pos = 0, cur = idx;
+    for (int p = parent[cur]; p >= 0; p = parent[cur]) {
+        const int2 c = children[p];
+        const bool sw = (swap_mask[p] >> ko) & 1;
+        const int first = sw ? c.y : c.x;
+        pos += 1 + (cur == first ? 0 : size_of(first));
+        cur = p;
+    }
+    const Box6 root = nbox[0], b = nbox[idx];
+    uint32_t w[3];
+    for (int a = 0; a < 3; a++) {
+        const float ext = root.mx[a] - root.mn[a];
+        const float scale = ext > 0.0f ? ext / 65535.0f : 1.0f;
+        if (g == 0) { q_params[a] = root.mn[a]; q_params[3 + a] = scale; }
+        const float lo = floorf((b.mn[a] - root.mn[a]) / scale) - 1.0f, hi = ceilf((b.mx[a] - root.mn[a]) / scale) + 1.0f;
+        const uint32_t qlo = (uint32_t)fminf(fmaxf(lo, 0.0f), 65535.0f), qhi = (uint32_t)fminf(fmaxf(hi, 0.0f), 65535.0f);
+        const bool neg = n_orders == 8 && ((k >> a) & 1);
+        w[a] = neg ? (qhi | (qlo << 16)) : (qlo | (qhi << 16));
+    }
+    const uint32_t last = idx < n - 1 ? (uint32_t)(pos + size_of(idx)) : (0x80000000u | (uint32_t)((idx - (n - 1)) * 8));
+    cnodes[(size_t)k * (size_t)nn + (size_t)pos] = make_uint4(w[0], w[1], w[2], last);
+}
+
 __global__ void k_bvh_init_bounds(int *bounds) {
     if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7FFFFFFF;
     else if (threadIdx.x < 6) bounds[threadIdx.x] = (int)0x80000000;
@@ -229,7 +265,7 @@ inline unsigned grid_for(long long n) { return (unsigned)((n + BB - 1) / BB); }
     } while (0)
 
 hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const int32_t *prim_host, const int32_t *mat_host, int n, bool ordered,
-                            float4 *nodes_dev, float4 *tris_dev, uint32_t *order_host) {
+                            float4 *nodes_dev, uint4 *cnodes_dev, float4 *tris_dev, uint32_t *order_host, float *q_params_host) {
     if (n <= 0) return hipSuccess;
     const int nn = 2 * n - 1, n_orders = ordered ? 8 : 1;
     float *tri_v = nullptr, *centroid = nullptr;
@@ -237,12 +273,13 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     Box6 *tbox = nullptr, *nbox = nullptr;
     unsigned long long *keys_in = nullptr, *keys_out = nullptr;
     int *bounds = nullptr, *parent = nullptr, *arrived = nullptr;
-    int2 *children = nullptr;
+    int2 *children = nullptr, *range = nullptr;
+    float *q_params = nullptr;
     unsigned char *swap_mask = nullptr;
     void *sort_tmp = nullptr;
     auto cleanup = [&]() {
         for (void *p : {(void *)tri_v, (void *)centroid, (void *)prim, (void *)mat, (void *)tbox, (void *)nbox, (void *)keys_in, (void *)keys_out, (void *)bounds,
-                        (void *)parent, (void *)arrived, (void *)children, (void *)swap_mask, sort_tmp})
+                        (void *)parent, (void *)arrived, (void *)children, (void *)range, (void *)q_params, (void *)swap_mask, sort_tmp})
             if (p) (void)hipFree(p);
     };
     BVH_TRY(hipMalloc((void **)&tri_v, 9 * sizeof(float) * (size_t)n));
@@ -257,6 +294,8 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     BVH_TRY(hipMalloc((void **)&parent, sizeof(int) * (size_t)nn));
     BVH_TRY(hipMalloc((void **)&arrived, sizeof(int) * (size_t)n));
     BVH_TRY(hipMalloc((void **)&children, sizeof(int2) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&range, sizeof(int2) * (size_t)n));
+    BVH_TRY(hipMalloc((void **)&q_params, 6 * sizeof(float)));
     BVH_TRY(hipMalloc((void **)&swap_mask, (size_t)n));
     size_t sort_bytes = 0;
     BVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys_out, n, 0, 62, stream));
@@ -272,7 +311,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     BVH_TRY(hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, keys_in, keys_out, n, 0, 62, stream));
     hipLaunchKernelGGL(k_bvh_emit_tris, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, prim, mat, keys_out, n, tbox, tris_dev, nbox);
     if (n > 1) {
-        hipLaunchKernelGGL(k_bvh_hierarchy, dim3(grid_for(n - 1)), dim3(BB), 0, stream, keys_out, n, children, parent);
+        hipLaunchKernelGGL(k_bvh_hierarchy, dim3(grid_for(n - 1)), dim3(BB), 0, stream, keys_out, n, children, parent, range);
         hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox);
         hipLaunchKernelGGL(k_bvh_order, dim3(grid_for(n - 1)), dim3(BB), 0, stream, n, children, nbox, swap_mask);
     } else {
@@ -281,7 +320,10 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
         BVH_TRY(hipStreamSynchronize(stream)); // minus_one goes out of scope
     }
     hipLaunchKernelGGL(k_bvh_thread, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, nbox, nodes_dev);
+    hipLaunchKernelGGL(k_bvh_compact, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, range, nbox, cnodes_dev,
+                       q_params);
     BVH_TRY(hipGetLastError());
+    BVH_TRY(hipMemcpyAsync(q_params_host, q_params, 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
     // the sorted order goes back to the host: it needs to know where each triangle's record went
     static_assert(sizeof(unsigned long long) == 8, "64-bit keys");
     unsigned long long *keys_host = nullptr;

@@ -118,6 +118,10 @@ struct DevLight {
 // link and miss, i.e. in the order children are visited.
 // Triangle, 48 B: (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, unused) with e1 = v1-v0, e2 = v2-v0.
 struct DevScene {
+    // the same tree in 16-byte nodes, one array per order, each in its own depth-first sequence (layout: rt_bvh.h); the
+    // planes are quantised to 16 bits over the root box: plane = q_lo + q * q_scale
+    const uint4 *cnodes;
+    float q_lo[3], q_scale[3];
     const float4 *nodes;
     const float4 *tris;
     const float4 *sph;      // cx cy cz r
@@ -128,6 +132,7 @@ struct DevScene {
     const DevLight *lights;
     const float *ltris;     // 9 floats per light triangle
     int32_t n_nodes, n_top, n_orders, n_tri, n_sph, n_cyl, n_light;
+    int32_t n_mat, n_light_tri;
     // Padded boxes around the big meshes.  A ray that touches one is expected to walk deep into the BVH ("heavy"), the
     // others ("light") can only meet triangles outside the big meshes; the queues keep the two kinds apart so that the
     // lanes of a wave have similar trip counts.  The test (ray_is_heavy) is conservative like the BVH's box test.
@@ -456,7 +461,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                                            float t_min, float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t NONE = 0xFFFFFFFFu;
-    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 32u);
+    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.cnodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 16u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
     const bool presorted = sc.n_orders == 8;
@@ -484,12 +489,11 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
             // one step of the walk for every lane that has a node; leaves are queued, not tested
             int leaf = -1;
             if (node >= 0) {
-                const u32x4 na = load16(node_r, g_base + (uint32_t)node * 32u);
-                const u32x4 nb = load16(node_r, g_base + (uint32_t)node * 32u + 16u);
+                const u32x4 nd = load16(node_r, g_base + (uint32_t)node * 16u);
                 if (COUNT) (*n_nodes)++;
-                const f32x2 tx = __builtin_elementwise_fma(f32x2{u2f(na.x), u2f(na.y)}, ix2, ox2);
-                const f32x2 ty = __builtin_elementwise_fma(f32x2{u2f(na.z), u2f(na.w)}, iy2, oy2);
-                const f32x2 tz = __builtin_elementwise_fma(f32x2{u2f(nb.x), u2f(nb.y)}, iz2, oz2);
+                const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(nd.x & 0xFFFFu), (float)(nd.x >> 16)}, ix2, ox2);
+                const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(nd.y & 0xFFFFu), (float)(nd.y >> 16)}, iy2, oy2);
+                const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(nd.z & 0xFFFFu), (float)(nd.z >> 16)}, iz2, oz2);
                 float tn, tf;
                 if (presorted) { // the node array of the ray's octant holds (entry plane, exit plane) per axis
                     tn = fmaxf(__builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x), t_min);
@@ -499,9 +503,11 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                     tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
                 }
                 const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
-                const int link = (int)nb.z, miss = (int)nb.w;
-                leaf = (inside && link < 0) ? ~link : -1;
-                node = (inside && link >= 0) ? link : miss;
+                const bool is_leaf = (int)nd.w < 0;
+                leaf = (inside && is_leaf) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
+                // depth-first order: the first child of an inner node and the successor of a leaf are the next node
+                const uint32_t nxt = (inside || is_leaf) ? (uint32_t)node + 1u : nd.w;
+                node = nxt < (uint32_t)sc.n_nodes ? (int)nxt : -1;
             }
             const unsigned long long m = __ballot(leaf >= 0);
             if (m != 0ull) {
@@ -585,13 +591,17 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 my_k = first + next + rank;
                 F3 o, d;
                 const bool walk = client.fetch(my_k, &o, &d);
-                const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z); // box tests only cull (padded boxes, widened exit)
-                ix2 = f32x2{ix, ix}; iy2 = f32x2{iy, iy}; iz2 = f32x2{iz, iz};
-                ox2 = f32x2{-o.x * ix, -o.x * ix}; oy2 = f32x2{-o.y * iy, -o.y * iy}; oz2 = f32x2{-o.z * iz, -o.z * iz};
+                // box tests only cull (padded boxes, quantised outwards, widened exit): distance to the plane of grid
+                // coordinate q along x = q * (q_scale.x / d.x) + (q_lo.x - o.x) / d.x, one packed multiply-add per axis
+                const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z);
+                const float ax = sc.q_scale[0] * ix, ay = sc.q_scale[1] * iy, az = sc.q_scale[2] * iz;
+                const float bx = (sc.q_lo[0] - o.x) * ix, by = (sc.q_lo[1] - o.y) * iy, bz = (sc.q_lo[2] - o.z) * iz;
+                ix2 = f32x2{ax, ax}; iy2 = f32x2{ay, ay}; iz2 = f32x2{az, az};
+                ox2 = f32x2{bx, bx}; oy2 = f32x2{by, by}; oz2 = f32x2{bz, bz};
                 // the octant is taken from the SIGN BITS (a component of -0 has a reciprocal of -inf): it decides which of a
                 // node's two planes per axis is the entry plane, and must agree with the sign of the reciprocal
                 const uint32_t octant = presorted ? ((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2)) : 0u;
-                g_base = octant * (uint32_t)sc.n_nodes * 32u;
+                g_base = octant * (uint32_t)sc.n_nodes * 16u;
                 wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
                 wl.ray_b[lane] = make_float2(d.y, d.z);
                 wl.best[lane] = (ANY_HIT && !walk) ? 0ull : key0;
@@ -651,8 +661,8 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)
-template <bool COUNT, bool USE_LDS = false, bool LOOSE = false>
-__device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
+template <bool COUNT, bool USE_LDS = false, bool LOOSE = false, class SC = DevScene>
+__device__ __forceinline__ bool world_occluded(const SC &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
                                                uint32_t *n_nodes, uint32_t *n_tris) {
     for (int i = 0; i < sc.n_sph; i++) {
         float t;
@@ -669,13 +679,17 @@ __device__ __forceinline__ bool world_occluded(const DevScene &sc, const float4 
 }
 
 // ------------------------------------------------------------------------------------------------ lights
-__device__ __forceinline__ F3 ltri_vertex(const DevScene &sc, int tri, int k) {
+// (the functions below that only read the small tables — lights, light triangles, materials, spheres, cylinders — take
+// the scene as a template parameter: the shading kernel hands them a view whose table pointers lead into LDS)
+template <class SC>
+__device__ __forceinline__ F3 ltri_vertex(const SC &sc, int tri, int k) {
     const float *p = sc.ltris + 9 * tri + 3 * k;
     return f3(p[0], p[1], p[2]);
 }
 
 // NaiveMesh::hit_both_side over a light's faces (mesh.rs:66-82)
-__device__ __forceinline__ bool light_mesh_hit(const DevScene &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+template <class SC>
+__device__ __forceinline__ bool light_mesh_hit(const SC &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
     bool any = false;
     float closest = t_max;
     for (int f = 0; f < L.tri_count; f++) {
@@ -691,7 +705,8 @@ __device__ __forceinline__ bool light_mesh_hit(const DevScene &sc, const DevLigh
 }
 
 // Light::hit: light.rs:101-103, 223-238, 344-346
-__device__ __forceinline__ bool light_hit(const DevScene &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+template <class SC>
+__device__ __forceinline__ bool light_hit(const SC &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
     if (L.kind == RT_LIGHT_DISK) {
         float hit_t = (L.oy - o.y) / d.y;
         if (hit_t < t_min) return false;
@@ -717,7 +732,8 @@ __device__ __forceinline__ bool light_hit(const DevScene &sc, const DevLight &L,
 }
 
 // LightList::_hit (light.rs:355-364): the FIRST light in list order that is hit, not the nearest
-__device__ __forceinline__ int lights_hit(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+template <class SC>
+__device__ __forceinline__ int lights_hit(const SC &sc, F3 o, F3 d, float t_min, float t_max, float *t_out) {
     for (int i = 0; i < sc.n_light; i++) {
         float t;
         if (light_hit(sc, sc.lights[i], o, d, t_min, t_max, &t)) { *t_out = t; return i; }

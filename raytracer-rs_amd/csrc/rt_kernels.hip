@@ -13,6 +13,8 @@
 
 #include "rt_kernels.h"
 
+#include <type_traits>
+
 namespace rtd {
 
 #define BLOCK 256
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
 }
 
 // ---- surface point ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void surface_at(const DevScene &sc, int code, F3 p, F3 *n, int *mat) {
+template <class SC>
+__device__ __forceinline__ void surface_at(const SC &sc, int code, F3 p, F3 *n, int *mat) {
     int idx = hit_index(code);
     switch (hit_kind(code)) {
     case HIT_KIND_TRI: {
@@ -407,7 +410,8 @@ __device__ __forceinline__ void surface_at(const DevScene &sc, int code, F3 p, F
     }
 }
 
-__device__ __forceinline__ F3 sample_in_triangle(const DevScene &sc, int tri, Stream &st) { // light.rs:274-288
+template <class SC>
+__device__ __forceinline__ F3 sample_in_triangle(const SC &sc, int tri, Stream &st) { // light.rs:274-288
     float e1 = st.next_f32();
     float e2 = st.next_f32();
     float se1 = sqrtf(e1);
@@ -417,7 +421,8 @@ __device__ __forceinline__ F3 sample_in_triangle(const DevScene &sc, int tri, St
 
 // LightList::visible_d without the occlusion query (light.rs:387-397 -> 83-95, 183-213, 303-332): picks a light,
 // samples it, returns direction, radiance and the light's pdf.  The caller queues the shadow ray.
-__device__ __forceinline__ bool nee_sample(const DevScene &sc, const RenderConst &rc, F3 p, F3 n, uint32_t pk, uint32_t nk, F3 *dir_out,
+template <class SC>
+__device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, F3 p, F3 n, uint32_t pk, uint32_t nk, F3 *dir_out,
                                            F3 *radiance, float *p_light) {
     if (sc.n_light == 0) return false;
     Stream st(pk, nk, P_NEE);
@@ -467,8 +472,8 @@ struct ShadeResult {
     uint32_t vis_pk = 0, vis_nk = 0;
 };
 
-template <int SHADER>
-__device__ __forceinline__ void shade_node(const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels, const Node &nd, float2 h,
+template <int SHADER, class SC>
+__device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, float *planes, uint32_t n_pixels, const Node &nd, float2 h,
                                            ShadeResult &r) {
     const float t_obj = h.x;
     const int code = __float_as_int(h.y);
@@ -594,7 +599,62 @@ __device__ __forceinline__ void append_shadow_classified(const DevScene &sc, con
 // ---- k_shade ---------------------------------------------------------------------------------------------------------
 // grid (blocks, RT_NSEG) like k_extend.  Children go to segment (bx + s) % RT_NSEG of the next queue, which spreads
 // every segment's offspring over all segments and keeps them level.
-template <int SHADER>
+// The small tables of a scene — lights and their triangles, materials, spheres, cylinders — are indexed per lane by the
+// shading code (the light a path picked, the material it hit).  From global memory every such access is one more vector
+// memory instruction through the texture addresser, about thirty per wave where five are needed for the path state; the
+// shading kernel was measured bound by exactly that.  When they fit (almost always) a workgroup copies them into LDS once.
+#define RT_TAB_LIGHTS 8
+#define RT_TAB_LTRIS 32
+#define RT_TAB_MATS 32
+#define RT_TAB_SPH 16
+#define RT_TAB_CYL 8
+struct ShadeTables {
+    DevLight lights[RT_TAB_LIGHTS];
+    float ltris[9 * RT_TAB_LTRIS];
+    rt_material mats[RT_TAB_MATS];
+    float4 sph[RT_TAB_SPH];
+    int2 sph_info[RT_TAB_SPH];
+    float cyl[5 * RT_TAB_CYL];
+    int2 cyl_info[RT_TAB_CYL];
+};
+static inline bool tables_fit(const DevScene &sc) {
+    return sc.n_light <= RT_TAB_LIGHTS && sc.n_light_tri <= RT_TAB_LTRIS && sc.n_mat <= RT_TAB_MATS && sc.n_sph <= RT_TAB_SPH && sc.n_cyl <= RT_TAB_CYL;
+}
+// The scene as the shading code sees it when the tables are staged: same member names as DevScene for what the
+// table-reading functions touch, everything else through the conversion to the scene itself.
+struct ShadeScene {
+    const DevScene &g;
+    const DevLight *lights;
+    const float *ltris;
+    const rt_material *mats;
+    const float4 *sph;
+    const int2 *sph_info;
+    const float *cyl;
+    const int2 *cyl_info;
+    const float4 *tris;
+    int32_t n_light, n_sph, n_cyl;
+    __device__ __forceinline__ operator const DevScene &() const { return g; }
+};
+// every thread of the workgroup must call it
+__device__ __forceinline__ ShadeScene stage_tables(const DevScene &sc, ShadeTables &tb) {
+    auto copy = [&](void *dst, const void *src, uint32_t bytes) {
+        uint32_t *d = static_cast<uint32_t *>(dst);
+        const uint32_t *s = static_cast<const uint32_t *>(src);
+#pragma unroll 1
+        for (uint32_t i = threadIdx.x; i < bytes / 4u; i += BLOCK) d[i] = s[i];
+    };
+    copy(tb.lights, sc.lights, (uint32_t)sc.n_light * (uint32_t)sizeof(DevLight));
+    copy(tb.ltris, sc.ltris, (uint32_t)sc.n_light_tri * 36u);
+    copy(tb.mats, sc.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material));
+    copy(tb.sph, sc.sph, (uint32_t)sc.n_sph * 16u);
+    copy(tb.sph_info, sc.sph_info, (uint32_t)sc.n_sph * 8u);
+    copy(tb.cyl, sc.cyl, (uint32_t)sc.n_cyl * 20u);
+    copy(tb.cyl_info, sc.cyl_info, (uint32_t)sc.n_cyl * 8u);
+    __syncthreads();
+    return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.n_light, sc.n_sph, sc.n_cyl};
+}
+
+template <int SHADER, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
@@ -609,9 +669,27 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     if (bx * BLOCK >= n_seg) return;
     const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
+    __shared__ typename std::conditional<LDS_TABLES, ShadeTables, char>::type tb;
 
     ShadeResult r;
-    if (il < n_seg) shade_node<SHADER>(sc, rc, planes, n_pixels, nd_early, h_early, r);
+    bool answered = false; // a light occlusion query answered in place, see below
+    bool s_heavy = false;  // the occlusion query's ray touches the box of a big mesh
+    auto shade = [&](const auto &view) {
+        if (il < n_seg) shade_node<SHADER>(view, rc, planes, n_pixels, nd_early, h_early, r);
+        s_heavy = SHADER != RT_SHADER_WHITTED && r.have_s && ray_is_heavy(sc, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min);
+        // A light occlusion query is a scan of the few loose triangles (and the spheres and cylinders): answered here, it
+        // costs neither the 40-byte store, nor the occlusion kernel's 40-byte load, nor a slot in the shadow queue.
+        if (SHADER != RT_SHADER_WHITTED && sc.inline_shadow && sc.n_loose >= 0) {
+            answered = r.have_s && !s_heavy;
+            if (__ballot(answered) != 0ull) {
+                uint32_t nn = 0, nt = 0;
+                const bool occ = answered && world_occluded<false, false, true>(view, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+                if (answered && !occ) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
+            }
+        }
+    };
+    if constexpr (LDS_TABLES) shade(stage_tables(sc, tb));
+    else shade(sc);
     const bool have0 = r.have0, have1 = r.have1, have_s = r.have_s, vis_pending = r.vis_pending;
     const Node &c0 = r.c0, &c1 = r.c1;
     const F3 s_o = r.s_o, s_d = r.s_d, s_c = r.s_c, vis_p = r.vis_p, vis_n = r.vis_n, vis_w = r.vis_w;
@@ -621,18 +699,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const bool heavy0 = have0 && ray_is_heavy(sc, c0.o, c0.d, rc.t_min, rc.t_max);
     const bool heavy1 = have1 && ray_is_heavy(sc, c1.o, c1.d, rc.t_min, rc.t_max);
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
-    const bool heavy_s = nee && ray_is_heavy(sc, s_o, s_d, rc.t_min, 1.0f - rc.t_min);
-    // A light occlusion query is a scan of the few loose triangles (and the spheres and cylinders): answered here, it
-    // costs neither the 40-byte store, nor the occlusion kernel's 40-byte load, nor a slot in the shadow queue.
-    bool answered = false;
-    if (SHADER != RT_SHADER_WHITTED && sc.inline_shadow && sc.n_loose >= 0) {
-        answered = nee && !heavy_s;
-        if (__ballot(answered) != 0ull) {
-            uint32_t nn = 0, nt = 0;
-            const bool occ = answered && world_occluded<false, false, true>(sc, nullptr, s_o, s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
-            if (answered && !occ) add_pixel(planes, n_pixels, s_pixel, s_c);
-        }
-    }
+    const bool heavy_s = nee && s_heavy;
     const bool queued = nee && !answered;
     const bool valid3[3] = {have0, have1, queued};
     const bool heavy3[3] = {heavy0, heavy1, heavy_s};
@@ -961,12 +1028,19 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (shader == RT_SHADER_MIS)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    const bool tab = tables_fit(sc);
+    if (shader == RT_SHADER_MIS && tab)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (shader == RT_SHADER_PATH && tab)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (tab)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_WHITTED, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (shader == RT_SHADER_MIS)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else if (shader == RT_SHADER_PATH)
-        hipLaunchKernelGGL(k_shade<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+        hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else
-        hipLaunchKernelGGL(k_shade<RT_SHADER_WHITTED>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+        hipLaunchKernelGGL((k_shade<RT_SHADER_WHITTED, false>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
 }
 
 void launch_shadow(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, ShadowQueue sh, float *planes, uint32_t n_pixels,

@@ -61,4 +61,6 @@ extern "C" {
     pub fn rt_params_default(p: *mut rt_params, width: i32, height: i32, spp: i32);
     pub fn rt_bvh_build_host(tri_v: *const f32, n_tri: i32, max_top: i32, ordered: i32, nodes_out: *mut f32, tris_out: *mut f32,
                              n_nodes: *mut i32, n_top: *mut i32, n_orders: *mut i32) -> i32;   // host-only diagnostic
+    pub fn rt_bvh_build_host_compact(tri_v: *const f32, n_tri: i32, ordered: i32, cnodes_out: *mut u32, q_params: *mut f32,
+                                     n_nodes: *mut i32, n_orders: *mut i32) -> i32;   // host-only diagnostic
 }

@@ -236,6 +236,16 @@ void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp)
 int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, int32_t ordered, float *nodes_out, float *tris_out,
                           int32_t *n_nodes, int32_t *n_top, int32_t *n_orders);
 
+/* Host-only diagnostic like rt_bvh_build_host, for the second node format rt_scene_create uploads: the same tree in
+ * 16-byte nodes, *n_orders arrays of *n_nodes nodes, each array in the depth-first order of its octant's visiting
+ * order (so the first child of an inner node is the next node).  Four uint32 per node: x, y, z = entry plane |
+ * exit plane << 16 for the rays of that octant, quantised to 16 bits over the root box and rounded outwards
+ * (plane = q_params[a] + q * q_params[3 + a] along axis a); w = inner node: index to continue with when the box is
+ * missed (*n_nodes = walk finished), leaf: 0x80000000 | first_triangle * 8 + count - 1 (triangle order: that of
+ * rt_bvh_build_host's tris_out).  cnodes_out may be NULL (sizes only). */
+int32_t rt_bvh_build_host_compact(const float *tri_v, int32_t n_tri, int32_t ordered, uint32_t *cnodes_out, float *q_params, int32_t *n_nodes,
+                                  int32_t *n_orders);
+
 #ifdef __cplusplus
 }
 #endif

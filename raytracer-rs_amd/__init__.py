@@ -345,6 +345,8 @@ def hip_lib() -> C.CDLL:
         lib.rt_params_default.restype = None
         lib.rt_bvh_build_host.argtypes = [c_float_p, C.c_int32, C.c_int32, C.c_int32, c_float_p, c_float_p, c_int32_p, c_int32_p, c_int32_p]
         lib.rt_bvh_build_host.restype = C.c_int32
+        lib.rt_bvh_build_host_compact.argtypes = [c_float_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), c_float_p, c_int32_p, c_int32_p]
+        lib.rt_bvh_build_host_compact.restype = C.c_int32
         _hip = lib
     return _hip
 
@@ -363,6 +365,18 @@ def bvh_build_host(tri_v: np.ndarray, max_top: int = 32, ordered: bool = True):
     tris = np.zeros((n, 12), np.float32)
     _check(lib.rt_bvh_build_host(_fp(tri_v), n, max_top, int(ordered), _fp(nodes), _fp(tris), C.byref(nn), C.byref(nt), C.byref(no)))
     return nodes, tris, nt.value
+
+
+def bvh_build_host_compact(tri_v: np.ndarray, ordered: bool = True):
+    """rt_bvh_build_host_compact: (cnodes (n_orders, n_nodes, 4) uint32, q_params (6,) float32 = q_lo xyz, q_scale xyz)."""
+    tri_v = np.ascontiguousarray(tri_v, np.float32).reshape(-1, 9)
+    nn, no = C.c_int32(), C.c_int32()
+    q = np.zeros(6, np.float32)
+    lib = hip_lib()
+    _check(lib.rt_bvh_build_host_compact(_fp(tri_v), tri_v.shape[0], int(ordered), None, _fp(q), C.byref(nn), C.byref(no)))
+    cn = np.zeros((no.value, nn.value, 4), np.uint32)
+    _check(lib.rt_bvh_build_host_compact(_fp(tri_v), tri_v.shape[0], int(ordered), cn.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(q), C.byref(nn), C.byref(no)))
+    return cn, q
 
 
 def _check(rc: int):

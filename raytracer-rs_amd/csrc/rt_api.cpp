@@ -306,6 +306,20 @@ int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, in
     return RT_OK;
 }
 
+int32_t rt_bvh_build_host_compact(const float *tri_v, int32_t n_tri, int32_t ordered, uint32_t *cnodes_out, float *q_params, int32_t *n_nodes,
+                                  int32_t *n_orders) {
+    if (n_tri < 0 || (n_tri > 0 && !tri_v)) return fail(RT_ERR_INVALID, "rt_bvh_build_host_compact: bad arguments");
+    std::vector<int32_t> prim((size_t)n_tri), mat((size_t)n_tri, 0);
+    for (int i = 0; i < n_tri; i++) prim[(size_t)i] = i;
+    BvhBuild b;
+    build_bvh(tri_v, prim.data(), mat.data(), n_tri, 0, ordered != 0, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &b);
+    if (n_nodes) *n_nodes = b.n_nodes;
+    if (n_orders) *n_orders = b.n_orders;
+    if (q_params) for (int a = 0; a < 3; a++) { q_params[a] = b.q_lo[a]; q_params[3 + a] = b.q_scale[a]; }
+    if (cnodes_out && !b.cnodes.empty()) std::memcpy(cnodes_out, b.cnodes.data(), b.cnodes.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 void rt_params_default(rt_params *p, int32_t width, int32_t height, int32_t spp) {
     std::memset(p, 0, sizeof(*p));
     p->width = width; p->height = height; p->spp = spp;

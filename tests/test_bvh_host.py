@@ -199,3 +199,90 @@ def test_empty_and_argument_errors(rt):
     assert nodes.shape[1] == 0 and tris.shape[0] == 0 and n_top == 0
     with pytest.raises(rt.RtError):
         rt.bvh_build_host(soup(3, 1), max_top=-1)
+
+
+# ---- the 16-byte copy of the tree (one load per visited node) -------------------------------------------------------------
+def walk_compact(cn, q, tris, octant, o, d, t_min, t_max, presorted):
+    """walk_range's step (rt_device.h) in numpy: planes from 16-bit grid coordinates, entry / exit already sorted for the
+    octant, first child = next node, w = where to go on after a miss."""
+    n = cn.shape[0]
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = (F(1.0) / d).astype(F)
+        a = (q[3:6] * inv).astype(F)
+        b = ((q[0:3] - o) * inv).astype(F)
+        best_t, best_p, node, visited = F(t_max), -1, 0, 0
+        while node < n:
+            visited += 1
+            assert visited <= n
+            w = cn[node]
+            e = ((w[:3] & 0xFFFF).astype(F) * a + b).astype(F)
+            x = ((w[:3] >> 16).astype(F) * a + b).astype(F)
+            if presorted:
+                tn, tf = np.fmax(np.fmax.reduce(e), F(t_min)), np.fmin(np.fmin.reduce(x), best_t)
+            else:
+                tn, tf = np.fmax(np.fmax.reduce(np.fmin(e, x)), F(t_min)), np.fmin(np.fmin.reduce(np.fmax(e, x)), best_t)
+            inside = tn <= F(tf * F(1.00001) + F(1e-7))
+            leaf = bool(w[3] >> 31)
+            if inside and leaf:
+                code = int(w[3] & 0x7FFFFFFF)
+                for k in range(code >> 3, (code >> 3) + (code & 7) + 1):
+                    t = tri_hit(tris[k, 0:3], tris[k, 4:7], tris[k, 8:11], o, d, t_min, t_max)
+                    if t is not None:
+                        p = int(tris[k, 3:4].view(np.int32)[0])
+                        if t < best_t or (t == best_t and p > best_p):
+                            best_t, best_p = t, p
+            node = node + 1 if (inside or leaf) else int(w[3])
+    return best_t, best_p, visited
+
+
+@pytest.mark.parametrize("n,ordered", [(1, True), (3, False), (200, True), (200, False), (1200, True)])
+def test_compact_nodes_structure_and_walk(rt, n, ordered):
+    tri_v = soup(n, n + 5, flat=(n == 200))
+    cn, q = rt.bvh_build_host_compact(tri_v, ordered=ordered)
+    nodes, tris, _ = rt.bvh_build_host(tri_v, max_top=0, ordered=ordered)
+    assert cn.shape[0] == nodes.shape[0] == (8 if ordered else 1) and cn.shape[1] == nodes.shape[1]
+    nn = cn.shape[1]
+    root_lo = np.sort(nodes[0, 0, :6].reshape(3, 2), axis=1)[:, 0]
+    assert np.allclose(q[:3], root_lo)
+    for k in range(cn.shape[0]):
+        c = cn[k]
+        leaf = (c[:, 3] >> 31).astype(bool)
+        skip = np.where(leaf, np.arange(nn) + 1, c[:, 3]).astype(np.int64)
+        # depth-first order: every subtree is the index range [i, skip[i]); ranges nest, the root's is everything
+        assert skip[0] == nn and (skip > np.arange(nn)).all() and (skip <= nn).all()
+        for i in range(nn):
+            if not leaf[i]:
+                j = i + 1
+                while j < skip[i]:  # the children: next node, then wherever each child's range ends
+                    assert skip[j] <= skip[i]
+                    lo_c, hi_c = np.minimum(c[j, :3] & 0xFFFF, c[j, :3] >> 16), np.maximum(c[j, :3] & 0xFFFF, c[j, :3] >> 16)
+                    lo_p, hi_p = np.minimum(c[i, :3] & 0xFFFF, c[i, :3] >> 16), np.maximum(c[i, :3] & 0xFFFF, c[i, :3] >> 16)
+                    assert (lo_c >= lo_p).all() and (hi_c <= hi_p).all()  # quantisation is monotone: children stay inside
+                    j = skip[j]
+                assert j == skip[i]
+        # every triangle in exactly one leaf; a leaf's dequantised box holds its triangles; entry/exit sorted for the octant
+        seen = []
+        for i in np.nonzero(leaf)[0]:
+            code = int(c[i, 3] & 0x7FFFFFFF)
+            first, count = code >> 3, (code & 7) + 1
+            seen += list(range(first, first + count))
+            v = np.concatenate([tris[first:first + count, 0:3], tris[first:first + count, 0:3] + tris[first:first + count, 4:7],
+                                tris[first:first + count, 0:3] + tris[first:first + count, 8:11]])
+            e = q[:3] + (c[i, :3] & 0xFFFF).astype(F) * q[3:]
+            x = q[:3] + (c[i, :3] >> 16).astype(F) * q[3:]
+            assert (np.minimum(e, x) <= v.min(0)).all() and (np.maximum(e, x) >= v.max(0)).all()
+            if ordered:
+                for a in range(3):
+                    assert (e[a] >= x[a]) if (k >> a) & 1 else (e[a] <= x[a])
+        assert sorted(seen) == list(range(n))
+    # the walk over the compact nodes finds the brute-force closest hit, in the ray's own octant (and, unsorted, in any)
+    rng = np.random.default_rng(n)
+    for _ in range(60 if n <= 200 else 25):
+        o = rng.uniform(-14, 14, 3).astype(F)
+        d = rng.normal(size=3).astype(F)
+        if rng.random() < 0.2:
+            d[rng.integers(3)] = F(0.0) * (F(-1.0) if rng.random() < 0.5 else F(1.0))  # +0 and -0 components
+        want = brute(tris, o, d, F(1e-3), F(1e7))
+        octant = int(np.signbit(d[0])) | (int(np.signbit(d[1])) << 1) | (int(np.signbit(d[2])) << 2) if ordered else 0
+        got = walk_compact(cn[octant], q, tris, octant, o, d, F(1e-3), F(1e7), presorted=ordered)
+        assert got[:2] == want, (o, d)

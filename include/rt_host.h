@@ -49,6 +49,14 @@ void rth_free(void *p);
  * from the raw integers of rt_resolve. */
 int32_t rth_write_ppm(const char *path, int32_t width, int32_t height, const int32_t *rgb_i32);
 
+/* The same image as an 8-bit RGB PNG (uncompressed deflate blocks, no library needed); values outside 0..255, which
+ * the P3 file keeps as they are, saturate.  The reference's renders are converted with external tools. */
+int32_t rth_write_png(const char *path, int32_t width, int32_t height, const int32_t *rgb_i32);
+
+/* Nearest-neighbour enlargement by an integer rate (resize.py:5-11, used for the chessboard sampler comparisons):
+ * out holds (width*rate) x (height*rate) x 3 values. */
+int32_t rth_upscale_nearest(int32_t width, int32_t height, int32_t rate, const int32_t *rgb_i32, int32_t *out);
+
 /*
  * Resumable accumulation.  The reference streams finished rows into its PPM (src/bin/main.rs:51), so a killed run
  * leaves a truncated image; here a render is a sum buffer plus the number of samples already added to it

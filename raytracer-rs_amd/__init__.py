@@ -134,6 +134,10 @@ def host_lib() -> C.CDLL:
         lib.rth_free.restype = None
         lib.rth_write_ppm.argtypes = [C.c_char_p, C.c_int32, C.c_int32, c_int32_p]
         lib.rth_write_ppm.restype = C.c_int32
+        lib.rth_write_png.argtypes = [C.c_char_p, C.c_int32, C.c_int32, c_int32_p]
+        lib.rth_write_png.restype = C.c_int32
+        lib.rth_upscale_nearest.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p]
+        lib.rth_upscale_nearest.restype = C.c_int32
         lib.rth_accum_save.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, c_float_p]
         lib.rth_accum_save.restype = C.c_int32
         lib.rth_accum_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32), c_float_p]
@@ -259,6 +263,26 @@ def write_ppm(path: str, rgb_i32: np.ndarray) -> None:
     rc = host_lib().rth_write_ppm(path.encode(), w, h, _ip(a))
     if rc != RT_OK:
         raise RtError(rc, host_lib().rth_last_error().decode())
+
+
+def write_png(path: str, rgb_i32: np.ndarray) -> None:
+    """rth_write_png: 8-bit RGB PNG of the integers of resolve(); values outside 0..255 saturate."""
+    h, w, _ = rgb_i32.shape
+    a = np.ascontiguousarray(rgb_i32, np.int32)
+    rc = host_lib().rth_write_png(path.encode(), w, h, _ip(a))
+    if rc != RT_OK:
+        raise RtError(rc, host_lib().rth_last_error().decode())
+
+
+def upscale_nearest(rgb_i32: np.ndarray, rate: int) -> np.ndarray:
+    """rth_upscale_nearest: every pixel repeated rate x rate times (resize.py:5-11)."""
+    h, w, _ = rgb_i32.shape
+    a = np.ascontiguousarray(rgb_i32, np.int32)
+    out = np.empty((h * max(rate, 0), w * max(rate, 0), 3), np.int32)
+    rc = host_lib().rth_upscale_nearest(w, h, rate, _ip(a), _ip(out))
+    if rc != RT_OK:
+        raise RtError(rc, host_lib().rth_last_error().decode())
+    return out
 
 
 def save_accum(path: str, accum: np.ndarray, spp: int, spp_done: int, seed: int = 1) -> None:

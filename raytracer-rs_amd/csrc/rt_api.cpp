@@ -629,10 +629,35 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         const size_t loose_max = env_u32_allow_zero("RT_LOOSE_MAX", 16);
         if (loose_max > 0 && by_prim.size() <= loose_max) {
             s->dev.n_loose = (int32_t)by_prim.size();
+            // Scale of everything a ray's end points can be: rays start on surfaces and end on lights.
+            double scale = 0.0;
+            auto grow = [&](double v) { scale = std::max(scale, std::fabs(v)); };
+            for (size_t i = 0; i < 9 * (size_t)d->n_tri; i++) grow(d->tri_v[i]);
+            for (int i = 0; i < d->n_sph; i++) for (int a = 0; a < 3; a++) grow(std::fabs(d->sph[4 * i + a]) + std::fabs(d->sph[4 * i + 3]));
+            for (int i = 0; i < d->n_cyl; i++) { grow(std::fabs(d->cyl[5 * i]) + std::fabs(d->cyl[5 * i + 4])); grow(std::fabs(d->cyl[5 * i + 1]) + std::fabs(d->cyl[5 * i + 4])); grow(d->cyl[5 * i + 2]); grow(d->cyl[5 * i + 3]); }
+            for (int i = 0; i < d->n_light; i++) for (int a = 0; a < 3; a++) grow(std::fabs(d->lights[i].origin[a]) + std::fabs(d->lights[i].radius));
+            for (size_t i = 0; i < 9 * (size_t)d->n_light_tri; i++) grow(d->light_tri_v[i]);
             for (const auto &pi : by_prim) {
                 const float *rec = &bvh.tris[12 * (size_t)pi.second];
                 loose.insert(loose.end(), rec, rec + 12);
                 std::memcpy(&loose[loose.size() - 1], &pi.second, sizeof(int32_t));
+                // Fourth word: the triangle's plane, scaled so that "farther than 1" means "safely off the plane" — an
+                // occlusion query whose segment starts behind it or ends in front of it by that margin cannot hit the
+                // front face, whatever the rounding of the exact test (loose_traverse).  Margin: 1e-4 of the scene's
+                // scale, more for slivers (the exact test's error grows with |E1||E2| / |E1 x E2|).
+                const double e1[3] = {rec[4], rec[5], rec[6]}, e2[3] = {rec[8], rec[9], rec[10]};
+                const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double nl = std::sqrt(nx * nx + ny * ny + nz * nz);
+                const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                float plane[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // degenerate triangle: never "safely off" — the exact test decides
+                if (nl > 0.0 && scale > 0.0 && std::isfinite(nl) && std::isfinite(scale)) {
+                    const double sliver = l1 * l2 / nl;
+                    const double margin = 1e-4 * scale * std::max(1.0, sliver / 10.0);
+                    const double k = 1.0 / (nl * margin);
+                    plane[0] = (float)(nx * k); plane[1] = (float)(ny * k); plane[2] = (float)(nz * k);
+                    plane[3] = (float)((nx * rec[0] + ny * rec[1] + nz * rec[2]) * k);
+                }
+                loose.insert(loose.end(), plane, plane + 4);
             }
         }
         UP(s->loose, loose.data(), loose.size() / 4, float4);

@@ -138,7 +138,8 @@ struct DevScene {
     // lanes of a wave have similar trip counts.  The test (ray_is_heavy) is conservative like the BVH's box test.
     int32_t n_heavy;
     // The triangles outside the big meshes, in primitive-id order, when they are few (n_loose >= 0; -1 = not in use):
-    // (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, index into tris).  A light ray is tested against all of them in a
+    // (v0.xyz, prim_id), (e1.xyz, material), (e2.xyz, index into tris), (the triangle's plane n.xyz, n.v0, scaled so that a
+    // signed distance beyond +-1 is safely off the plane).  A light ray is tested against all of them in a
     // loop the whole wave runs together (the reference's own scan of the world list, hitable.rs:44-50) instead of walking the BVH.
     const float4 *loose;
     int32_t n_loose;
@@ -621,8 +622,22 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
 template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_tris) {
     TriHit best{t_max, -1, -1};
+    // An occlusion query over the segment t in [t_min, t_max] within [0, 1] can only hit a FRONT face whose plane the
+    // segment crosses from front to back: with the start behind the plane, or the end in front of it, by the margin the
+    // host scaled the plane with (1e-4 of the scene's size, more for slivers: far above the rounding of the exact test,
+    // so the exact test would reject as well), the triangle is skipped — and when that holds for every lane of the wave
+    // the exact test (50 instructions with its division) is not run at all.  In a closed room that is almost every
+    // triangle for almost every wave.  NaN coordinates compare false: never skipped.
+    const bool may_skip = ANY_HIT && t_min >= 0.0f && t_max <= 1.0f;
     for (int k = 0; k < sc.n_loose; k++) {
-        const float4 a = sc.loose[3 * k], b = sc.loose[3 * k + 1], c = sc.loose[3 * k + 2];
+        if (may_skip) {
+            const float4 pl = sc.loose[4 * k + 3];
+            const float da = __builtin_fmaf(pl.x, o.x, __builtin_fmaf(pl.y, o.y, __builtin_fmaf(pl.z, o.z, -pl.w)));
+            const float db = da + __builtin_fmaf(pl.x, d.x, __builtin_fmaf(pl.y, d.y, pl.z * d.z));
+            const bool off = da <= -1.0f || db >= 1.0f;
+            if (__ballot(!off) == 0ull) continue;
+        }
+        const float4 a = sc.loose[4 * k], b = sc.loose[4 * k + 1], c = sc.loose[4 * k + 2];
         if (COUNT) (*n_tris)++;
         float t;
         if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {

@@ -4,12 +4,15 @@
 #include "rt_host.hpp"
 #include "../../include/rt_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <string>
+#include <vector>
 
 namespace rt {
 
@@ -618,6 +621,92 @@ int32_t rth_write_ppm(const char *path, int32_t w, int32_t h, const int32_t *rgb
     std::fprintf(f, "P3\n%d %d\n255\n", w, h); // main.rs:27
     for (int64_t i = 0; i < (int64_t)w * h; i++) std::fprintf(f, "%d %d %d\n", rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]); // main.rs:51
     std::fclose(f);
+    return RT_OK;
+}
+
+namespace {
+// CRC-32 of PNG chunks (polynomial 0xEDB88320), table built on first use
+uint32_t png_crc(uint32_t crc, const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+bool png_chunk(FILE *f, const char type[4], const std::vector<uint8_t> &data) {
+    std::vector<uint8_t> head;
+    put_be32(head, (uint32_t)data.size());
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = png_crc(0u, head.data() + 4, 4);
+    crc = png_crc(crc, data.data(), data.size());
+    std::vector<uint8_t> tail;
+    put_be32(tail, crc);
+    return std::fwrite(head.data(), 1, 8, f) == 8 && (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+} // namespace
+
+// resize.py:8-11: pixel (i, j) of the enlarged image is pixel (i / rate, j / rate) of the source
+int32_t rth_upscale_nearest(int32_t w, int32_t h, int32_t rate, const int32_t *rgb, int32_t *out) {
+    if (!rgb || !out || w <= 0 || h <= 0 || rate <= 0 || (int64_t)w * rate > 65535 || (int64_t)h * rate > 65535) { g_host_err = "rth_upscale_nearest: bad argument"; return RT_ERR_INVALID; }
+    const int64_t W = (int64_t)w * rate;
+    for (int64_t y = 0; y < (int64_t)h * rate; y++) {
+        const int32_t *src = rgb + (y / rate) * w * 3;
+        int32_t *dst = out + y * W * 3;
+        for (int64_t x = 0; x < W; x++) {
+            const int32_t *s = src + (x / rate) * 3;
+            dst[3 * x] = s[0]; dst[3 * x + 1] = s[1]; dst[3 * x + 2] = s[2];
+        }
+    }
+    return RT_OK;
+}
+
+int32_t rth_write_png(const char *path, int32_t w, int32_t h, const int32_t *rgb) {
+    if (!path || !rgb || w <= 0 || h <= 0) { g_host_err = "rth_write_png: bad argument"; return RT_ERR_INVALID; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { g_host_err = std::string("cannot create ") + path; return RT_ERR_INVALID; }
+    // rows of (filter byte 0, RGB bytes); values above 255 (the reference's cast does not clamp, main.rs:48-50) saturate
+    const size_t row = 1 + (size_t)w * 3;
+    std::vector<uint8_t> raw(row * (size_t)h);
+    for (int32_t y = 0; y < h; y++) {
+        uint8_t *r = raw.data() + row * y;
+        r[0] = 0;
+        for (int64_t i = 0; i < (int64_t)w * 3; i++) {
+            const int32_t v = rgb[(int64_t)y * w * 3 + i];
+            r[1 + i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+    // zlib stream of stored blocks (deflate type 0, at most 65535 bytes each) with its Adler-32
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = pos; i < pos + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+        if (n == 0) break;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); // 8 bits, RGB, no interlace
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    bool ok = std::fwrite(sig, 1, 8, f) == 8 && png_chunk(f, "IHDR", ihdr) && png_chunk(f, "IDAT", z) && png_chunk(f, "IEND", {});
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { g_host_err = std::string("cannot write ") + path; return RT_ERR_INVALID; }
     return RT_OK;
 }
 

@@ -295,6 +295,43 @@ def test_tie_backface_and_degenerate_triangles(rt, orc, gpu_ctx):
     ds.close()
 
 
+@pytest.mark.parametrize("shader_name", ["SHADER_WHITTED", "SHADER_MIS"])
+def test_occluders_next_to_the_ends_of_shadow_segments(rt, orc, gpu_ctx, shader_name):
+    """Occlusion queries over a short triangle list skip a triangle when a whole wave's segments lie clearly on one side
+    of its plane.  An occluder just inside the far end of every segment (t < 1 - T_MIN, src/light.rs:74), one just
+    outside it, one behind the light, a needle-thin one, one of zero area and one standing on the floor (segments start
+    next to its edge) must occlude exactly what the reference's test (src/geometry.rs:29-55) says they do."""
+    floor = [[-2, -1, 0, 2, -1, 0, 2, -1, -4], [-2, -1, 0, 2, -1, -4, -2, -1, -4]]
+    ly = 0.5
+
+    def under_light(dy):  # faces down: rays going up meet its front
+        return [-0.3, ly - dy, -1.7, 0.0, ly - dy, -2.3, 0.3, ly - dy, -1.7]
+
+    inside = under_light(4e-3)    # t = 1 - 4e-3/1.5 or less for floor points: occludes
+    outside = under_light(5e-4)   # t = 1 - 3.3e-4 > 1 - T_MIN for floor points: does not
+    above = [-0.3, ly + 1e-6, -1.7, 0.0, ly + 1e-6, -2.3, 0.3, ly + 1e-6, -1.7]
+    needle = [-1.5, -0.2, -2.0, 1.5, -0.2 + 1e-5, -2.00001, 1.5, -0.2, -2.0]
+    zero = [0.5, 0, -2, 0.5, 0, -2, 0.7, 0.2, -2]
+    standing = [-1.0, -1, -3.0, -0.4, -1, -3.0, -0.7, -0.3, -3.0]
+    cam = rt.camera_new((0, 0.3, 2), (0, -0.5, -2), (0, 1, 0), 90.0, 1.0)
+    p = rt.default_params(64, 64, 2, shader=getattr(rt, shader_name))
+    lit = {}
+    for name, extra in (("dark", [inside, outside, above, needle, zero, standing]), ("lit", [outside, above, needle, zero, standing])):
+        tri_v = np.array(floor + extra, np.float32)
+        sc = rt.NumpyScene(tri_v=tri_v, tri_mat=[0] * len(tri_v), mats=[rt.diffuse(0.8, 0.8, 0.8)],
+                           lights=[rt.Light(rt.LIGHT_POINT, (0.0, ly, -2.0), 0, (9, 9, 9), 0, 0, 1)])
+        ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+        osc = orc.OracleScene(sc.desc, 0, sc)
+        ga, _ = ds.render(cam, p)
+        ca, _ = osc.render(cam, p)
+        assert_radiance_close(ga, ca)
+        prim = osc.primary_hits(cam, p)[0].reshape(-1)
+        on_floor = (prim >= 0) & (prim < 2)
+        lit[name] = float(ca.reshape(-1, 3)[on_floor].sum())
+        ds.close()
+    assert lit["lit"] > 0 and lit["dark"] < 0.05 * lit["lit"]
+
+
 def test_axis_aligned_cube_is_intact(rt, orc, gpu_ctx):
     """cube.obj has only axis-aligned faces: their boxes are flat.  The reference's BVH can never hit a flat box
     (src/mesh.rs:117); here every mesh returns the brute-force result, so all faces the camera sees are hit."""

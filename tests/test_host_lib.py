@@ -155,3 +155,33 @@ def test_accumulation_files_round_trip_and_refuse_a_different_render(rt, tmp_pat
         rt.load_accum(str(tmp_path / "missing"), 7, 5, 64, seed=9)
     with pytest.raises(rt.RtError):
         rt.save_accum(path, a, spp=64, spp_done=65, seed=9)
+
+
+def test_png_file_is_read_back_by_an_independent_decoder(rt, tmp_path):
+    """rth_write_png: stored-deflate PNG; PIL decodes it to the same bytes, values outside 0..255 saturated
+    (the P3 file of src/bin/main.rs:48-51 keeps them)."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    for h, w in ((1, 1), (3, 5), (160, 213)):  # the last one needs more than one 65535-byte deflate block
+        a = rng.integers(0, 256, (h, w, 3)).astype(np.int32)
+        a[0, 0] = (-7, 300, 255)
+        path = str(tmp_path / f"img_{h}x{w}.png")
+        rt.write_png(path, a)
+        back = np.asarray(Image.open(path).convert("RGB"), np.int32)
+        assert back.shape == a.shape and np.array_equal(back, np.clip(a, 0, 255))
+    with pytest.raises(rt.RtError, match="cannot create"):
+        rt.write_png(str(tmp_path / "no_such_dir" / "x.png"), a)
+
+
+def test_upscale_repeats_pixels_like_the_reference_script(rt):
+    """resize.py:8-11: new(i, j) = old(i // RATE, j // RATE)."""
+    rng = np.random.default_rng(6)
+    a = rng.integers(0, 400, (7, 5, 3)).astype(np.int32)
+    for rate in (1, 4, 8):
+        big = rt.upscale_nearest(a, rate)
+        assert big.shape == (7 * rate, 5 * rate, 3)
+        jj, ii = np.mgrid[0:7 * rate, 0:5 * rate]
+        assert np.array_equal(big, a[jj // rate, ii // rate])
+    with pytest.raises(rt.RtError):
+        rt.upscale_nearest(a, 0)

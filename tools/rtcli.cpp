@@ -2,12 +2,14 @@
 //
 //   rtcli <light-sampler 1..4> [--scene head] [--width 800] [--height 800] [--spp 800] [--shader mis|path|whitted|normal]
 //         [--pixel-sampler 1..4] [--seed 1] [--device 0] [--assets assets] [--out ./output/out.ppm] [--batch N]
-//         [--resume FILE] [--stop-after N]
+//         [--resume FILE] [--stop-after N] [--upscale RATE]
 //
 // argv[1] keeps its meaning (SamplerKind::from_int for the light sampler, main.rs:15-18); the compile-time constants
 // NX, NY, NS of src/lib.rs:21-23 and the scene / shader chosen by (un)commenting code (main.rs:20-23,40-43) are
 // flags.  Output: the same ASCII P3 file (main.rs:27,51) and the same progress / "Finished." lines (main.rs:53-61),
 // printed per batch of samples instead of per five rows because the image is rendered a sample range at a time.
+// An --out name ending in .png gives an 8-bit PNG instead; --upscale enlarges the image by pixel repetition first
+// (the job of resize.py for the sampler comparison images).
 
 #include <chrono>
 #include <cstdio>
@@ -23,7 +25,8 @@ static int usage() {
     std::fprintf(stderr, "usage: rtcli <light-sampler 1..4> [--scene NAME] [--width W] [--height H] [--spp N] [--shader mis|path|whitted|normal]\n"
                          "             [--pixel-sampler 1..4] [--seed S] [--device D] [--assets DIR] [--out FILE] [--batch N]\n"
                          "             [--resume FILE: sums + samples done, saved after every batch, picked up if present]\n"
-                         "             [--stop-after N: leave after N samples per pixel (with --resume: continue later)]\n");
+                         "             [--stop-after N: leave after N samples per pixel (with --resume: continue later)]\n"
+                         "             [--upscale RATE: repeat every pixel RATE x RATE times]   (--out FILE.png writes a PNG)\n");
     return 2;
 }
 
@@ -32,7 +35,7 @@ int main(int argc, char **argv) {
     if (argc < 2) return usage();
     int light_sampler = std::atoi(argv[1]);
     std::string scene = "head", shader = "mis", assets = "assets", out = "./output/out.ppm", resume;
-    int width = 800, height = 800, spp = 800, pixel_sampler = RT_SAMPLER_BLUE, device = 0, batch = 0, stop_after = 0;
+    int width = 800, height = 800, spp = 800, pixel_sampler = RT_SAMPLER_BLUE, device = 0, batch = 0, stop_after = 0, upscale = 1;
     unsigned seed = 1;
     for (int i = 2; i + 1 < argc; i += 2) {
         std::string k = argv[i], v = argv[i + 1];
@@ -49,6 +52,7 @@ int main(int argc, char **argv) {
         else if (k == "--batch") batch = std::atoi(v.c_str());
         else if (k == "--resume") resume = v;
         else if (k == "--stop-after") stop_after = std::atoi(v.c_str());
+        else if (k == "--upscale") upscale = std::atoi(v.c_str());
         else return usage();
     }
     if (light_sampler < 1 || light_sampler > 4) { // SamplerKind::from_int, sampler.rs:13-21
@@ -114,7 +118,18 @@ int main(int argc, char **argv) {
     }
     std::vector<int32_t> rgb((size_t)width * height * 3);
     rt_resolve(accum.data(), (int64_t)width * height, spp, rgb.data(), nullptr);
-    if (rth_write_ppm(out.c_str(), width, height, rgb.data()) != RT_OK) {
+    if (upscale > 1) {
+        std::vector<int32_t> big((size_t)width * upscale * height * upscale * 3);
+        if (rth_upscale_nearest(width, height, upscale, rgb.data(), big.data()) != RT_OK) {
+            std::fprintf(stderr, "Error: %s\n", rth_last_error());
+            return 1;
+        }
+        rgb.swap(big);
+        width *= upscale;
+        height *= upscale;
+    }
+    const bool png = out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if ((png ? rth_write_png(out.c_str(), width, height, rgb.data()) : rth_write_ppm(out.c_str(), width, height, rgb.data())) != RT_OK) {
         std::fprintf(stderr, "Error: %s\n", rth_last_error());
         return 1;
     }

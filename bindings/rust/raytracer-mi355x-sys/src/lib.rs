@@ -38,6 +38,11 @@ pub const RT_ERR_NOMEM: i32 = 4;
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct rt_scene_info { pub n_triangles: i32, pub n_nodes: i32, pub n_orders: i32,
     pub n_top: i32, pub bvh_on_device: i32, pub reserved: i32, pub bvh_build_ms: f64 }
 pub const RT_SCENE_BVH_ON_DEVICE: u32 = 1;
+pub const RT_FLAG_TIMING: u32 = 1;
+pub const RT_FLAG_COUNT_WORK: u32 = 2;
+pub const RT_FLAG_RUSSIAN_ROULETTE: u32 = 4;
+pub const RT_FLAG_COSINE_DIFFUSE: u32 = 8;
+pub const RT_RR_MIN_DEPTH: i32 = 3;
 pub enum rt_context {}
 pub enum rt_scene {}
 

@@ -110,8 +110,19 @@ enum { RT_SHADER_NORMAL = 0, RT_SHADER_WHITTED = 1, RT_SHADER_PATH = 2, RT_SHADE
 
 enum {
     RT_FLAG_TIMING = 1, /* time every kernel launch with HIP events on the render stream and fill rt_stats.ms_* */
-    RT_FLAG_COUNT_WORK = 2 /* count BVH node visits and primitive tests (slower; fills rt_stats.nodes/tris) */
+    RT_FLAG_COUNT_WORK = 2, /* count BVH node visits and primitive tests (slower; fills rt_stats.nodes/tris) */
+    /* Options the reference does not have; off by default, results then follow the reference.  MIS and path shaders only
+     * (the Whitted and normal shaders ignore them). */
+    RT_FLAG_RUSSIAN_ROULETTE = 4, /* a scattered ray at depth >= RT_RR_MIN_DEPTH survives with probability q = largest
+                                     component of the material's attenuation, clamped to [0.05, 1], and is weighted 1/q:
+                                     same expectation as src/shader.rs:93-115, shorter paths */
+    RT_FLAG_COSINE_DIFFUSE = 8    /* Diffuse surfaces scatter with density cos/pi (direction = normal + point on the unit
+                                     sphere) and the cosine enters the scattered ray's weight, instead of the uniform
+                                     hemisphere with nominal density 1/pi of src/material.rs:85-103,144-151: changes the
+                                     expectation (towards the rendering equation's) */
 };
+
+#define RT_RR_MIN_DEPTH 3
 
 typedef struct rt_params {
     int32_t width, height;      /* NX, NY (src/lib.rs:21-22) */

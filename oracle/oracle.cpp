@@ -105,7 +105,7 @@ inline uint32_t root_node_key(uint32_t sample) { return mix32(sample + 0x6A09E66
 // branch 0: the ray sampled from the BSDF; branch 1: Microfacet's extra diffuse ray (material.rs:416-438)
 inline uint32_t child_node_key(uint32_t nk, uint32_t branch) { return mix32(nk + 0xBB67AE85U * (branch + 1U)); }
 
-enum Purpose : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_VISIBLE0 = 16 };
+enum Purpose : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_ROULETTE = 5, P_ROULETTE1 = 6, P_VISIBLE0 = 16 };
 
 struct Stream {
     uint32_t pk, sk, j;
@@ -992,6 +992,29 @@ struct Ctx {
 
 V3 path_trace_shader_mis(const Ctx &cx, const Ray &r, int depth, uint32_t nk);
 
+// ---- options beyond the reference (rt_params.flags; off by default) ---------------------------------------------------
+// RT_FLAG_RUSSIAN_ROULETTE: the recursion into a scattered ray at depth >= RT_RR_MIN_DEPTH happens with probability
+// q = largest component of the material's attenuation, clamped to [0.05, 1], and its result is divided by q.
+// Returns false when the ray dies; *q is 1 when roulette does not apply.
+bool roulette(const Ctx &cx, const rt_material &m, uint32_t nk, uint32_t dim, int child_depth, float *q) {
+    *q = 1.0f;
+    if (!(cx.pr.flags & RT_FLAG_RUSSIAN_ROULETTE) || child_depth < RT_RR_MIN_DEPTH) return true;
+    V3 a = mat_attenuation(m);
+    *q = std::fmin(1.0f, std::fmax(std::fmax(a.x, std::fmax(a.y, a.z)), 0.05f));
+    Stream st(cx.pk, nk, dim);
+    return st.next_f32() < *q;
+}
+inline bool roulette_applies(const Ctx &cx, int child_depth) { return (cx.pr.flags & RT_FLAG_RUSSIAN_ROULETTE) && child_depth >= RT_RR_MIN_DEPTH; }
+// RT_FLAG_COSINE_DIFFUSE: Diffuse surfaces scatter along normalize(n + point on the unit sphere), density cos/pi
+inline bool cosine_diffuse(const Ctx &cx, const rt_material &m) { return (cx.pr.flags & RT_FLAG_COSINE_DIFFUSE) && m.kind == RT_MAT_DIFFUSE; }
+V3 cosine_scatter(V3 n, uint32_t pk, uint32_t nk) {
+    Stream st(pk, nk, P_SCATTER);
+    V3 nn = normalize(n);
+    V3 d = nn + unit_vec_on_sphere(st);
+    return dot(d, d) < 1e-12f ? nn : normalize(d);
+}
+inline float cosine_of(V3 d, V3 n) { return std::fmax(dot(normalize(d), normalize(n)), 0.0f); }
+
 // the common prologue of shader.rs:28-30, 64-66, 99-101: returns 0 = object is shaded, 1 = light spectrum, 2 = black
 int closer_of(const Ctx &cx, const Ray &r, Hit *rec, V3 *light) {
     cx.cn->closest++;
@@ -1044,9 +1067,14 @@ V3 path_trace_shader(const Ctx &cx, const Ray &r, int depth, uint32_t nk) {
     if (w == 2) return BLACK;
     const rt_material &m = cx.sc.mats[rec.mat];
     Ray scattered;
-    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+    bool scat;
+    if (cosine_diffuse(cx, m)) { scattered = Ray{rec.p, cosine_scatter(rec.n, cx.pk, nk)}; scat = true; }
+    else scat = mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered);
+    float q;
+    if (scat && roulette(cx, m, nk, P_ROULETTE, depth + 1, &q)) {
         V3 t = path_trace_shader(cx, scattered, depth + 1, child_node_key(nk, 0));
-        return mul_v(t, mat_attenuation(m));
+        V3 res = mul_v(t, mat_attenuation(m));
+        return roulette_applies(cx, depth + 1) ? res / q : res;
     }
     return BLACK;
 }
@@ -1056,6 +1084,7 @@ V3 direct_term(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec
     LSample ls;
     if (lights_visible_d(cx.sc, rec.p, rec.n, cx.pr, cx.pk, nk, cx.cn, &ls)) {
         float b_pdf = mat_pdf(m, r.d, ls.ray.d, rec.n, cx.pr.t_min);
+        if (cosine_diffuse(cx, m)) b_pdf = cosine_of(ls.ray.d, rec.n) * (1.0f / PI);
         return mul_v(ls.radiance, mat_brdf(m, r.d, ls.ray.d, rec.n, cx.pr.t_min)) / (ls.p + b_pdf);
     }
     return BLACK;
@@ -1065,11 +1094,23 @@ V3 direct_term(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec
 V3 do_material_default(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, int depth, uint32_t nk) {
     V3 brdf = BLACK;
     Ray scattered;
-    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+    const bool cosine = cosine_diffuse(cx, m);
+    bool scat;
+    if (cosine) { scattered = Ray{rec.p, cosine_scatter(rec.n, cx.pk, nk)}; scat = true; }
+    else scat = mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered);
+    float q;
+    if (scat && roulette(cx, m, nk, P_ROULETTE, depth + 1, &q)) {
         V3 li = path_trace_shader_mis(cx, scattered, depth + 1, child_node_key(nk, 0));
         float l_pdf = lights_pdf(cx.sc, scattered, cx.pr);
         float b_pdf = mat_pdf(m, r.d, scattered.d, rec.n, cx.pr.t_min);
-        brdf = mul_v(li, mat_brdf(m, r.d, scattered.d, rec.n, cx.pr.t_min)) / (l_pdf + b_pdf);
+        V3 f = mat_brdf(m, r.d, scattered.d, rec.n, cx.pr.t_min);
+        if (cosine) {
+            float c = cosine_of(scattered.d, rec.n);
+            f = f * c;
+            b_pdf = c * (1.0f / PI);
+        }
+        brdf = mul_v(li, f) / (l_pdf + b_pdf);
+        if (roulette_applies(cx, depth + 1)) brdf = brdf / q;
     }
     V3 direct = direct_term(cx, m, r, rec, nk);
     return brdf + direct;
@@ -1079,11 +1120,13 @@ V3 do_material_default(const Ctx &cx, const rt_material &m, const Ray &r, const 
 V3 do_material_microfacet(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, int depth, uint32_t nk) {
     V3 specular = BLACK;
     Ray scattered;
-    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered)) {
+    float q;
+    if (mat_scatter_d(m, r, rec, cx.pr.t_min, cx.pk, nk, &scattered) && roulette(cx, m, nk, P_ROULETTE, depth + 1, &q)) {
         V3 li = path_trace_shader_mis(cx, scattered, depth + 1, child_node_key(nk, 0));
         float l_pdf = lights_pdf(cx.sc, scattered, cx.pr);
         float b_pdf = mat_pdf(m, r.d, scattered.d, rec.n, cx.pr.t_min);
         specular = mul_v(li, mat_brdf(m, r.d, scattered.d, rec.n, cx.pr.t_min)) / (l_pdf + b_pdf);
+        if (roulette_applies(cx, depth + 1)) specular = specular / q;
     }
     V3 kd, diffuse;
     {
@@ -1097,10 +1140,14 @@ V3 do_material_microfacet(const Ctx &cx, const rt_material &m, const Ray &r, con
         V3 f = fresnel_schlick(wi, wg, f0);
         kd = (v3(1.0f, 1.0f, 1.0f) - f) * (1.0f - m.metallic);
         int dd = std::max(depth, cx.pr.max_depth - 6); // material.rs:433: depth.max(34) with max_depth = 40
-        V3 li = path_trace_shader_mis(cx, sc2, dd + 1, child_node_key(nk, 1));
-        float l_pdf = lights_pdf(cx.sc, sc2, cx.pr);
-        float b_pdf = 1.0f / PI;
-        diffuse = mul_v(li, albedo_of(m) / PI) / (l_pdf + b_pdf);
+        float q1;
+        if (roulette(cx, m, nk, P_ROULETTE1, dd + 1, &q1)) {
+            V3 li = path_trace_shader_mis(cx, sc2, dd + 1, child_node_key(nk, 1));
+            float l_pdf = lights_pdf(cx.sc, sc2, cx.pr);
+            float b_pdf = 1.0f / PI;
+            diffuse = mul_v(li, albedo_of(m) / PI) / (l_pdf + b_pdf);
+            if (roulette_applies(cx, dd + 1)) diffuse = diffuse / q1;
+        } else diffuse = BLACK;
     }
     V3 brdf = mul_v(kd, diffuse) + specular;
     V3 direct = direct_term(cx, m, r, rec, nk);

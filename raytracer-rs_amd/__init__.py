@@ -29,6 +29,8 @@ SAMPLER_WHITE, SAMPLER_UNIFORM, SAMPLER_JITTERED, SAMPLER_BLUE = 1, 2, 3, 4
 OBJ_TRIANGLE, OBJ_SPHERE, OBJ_CYLINDER, OBJ_MESH = 0, 1, 2, 3
 SHADER_NORMAL, SHADER_WHITTED, SHADER_PATH, SHADER_MIS = 0, 1, 2, 3
 FLAG_TIMING, FLAG_COUNT_WORK = 1, 2
+FLAG_RUSSIAN_ROULETTE, FLAG_COSINE_DIFFUSE = 4, 8  # options the reference does not have (off by default)
+RR_MIN_DEPTH = 3
 SCENE_BVH_ON_DEVICE = 1
 
 c_float_p = C.POINTER(C.c_float)

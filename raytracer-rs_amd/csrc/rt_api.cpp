@@ -194,6 +194,7 @@ RenderConst make_const(const rt_camera &cam, const rt_params &p) {
     rc.spp_edge = (int)std::sqrt((double)p.spp);           // sampler.rs:104
     rc.ns2_edge = (int)std::sqrt((double)p.light_samples);
     rc.t_min = p.t_min; rc.t_max = p.t_max; rc.seed = p.seed;
+    rc.flags = p.flags & (RT_FLAG_RUSSIAN_ROULETTE | RT_FLAG_COSINE_DIFFUSE);
     rc.tiles_w = (uint32_t)((p.width + 7) / 8);
     rc.plane_stride = 64u * rc.tiles_w * (uint32_t)((p.height + 7) / 8);
     rc.w_magic = ((1ull << 40) + (unsigned long long)p.width - 1ull) / (unsigned long long)p.width;

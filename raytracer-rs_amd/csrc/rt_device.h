@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t pixel_key(uint32_t seed, uint32_t pixel) { r
 __device__ __forceinline__ uint32_t root_node_key(uint32_t sample) { return mix32(sample + 0x6A09E667U); }
 __device__ __forceinline__ uint32_t child_node_key(uint32_t nk, uint32_t branch) { return mix32(nk + 0xBB67AE85U * (branch + 1U)); }
 
-enum : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_VISIBLE0 = 16 };
+enum : uint32_t { P_CAMERA = 1, P_SCATTER = 2, P_DIFFUSE = 3, P_NEE = 4, P_ROULETTE = 5, P_ROULETTE1 = 6, P_VISIBLE0 = 16 };
 
 struct Stream {
     uint32_t pk, sk, j;
@@ -180,6 +180,7 @@ struct RenderConst {
     int32_t spp_edge, ns2_edge; // floor(sqrt(spp)), floor(sqrt(light_samples)): UniformSampler::new, sampler.rs:104
     float t_min, t_max;
     uint32_t seed;
+    uint32_t flags; // RT_FLAG_RUSSIAN_ROULETTE, RT_FLAG_COSINE_DIFFUSE
     // accumulation planes are stored in 8x8 pixel tiles (64 consecutive floats per tile): the lanes of a wave mostly
     // work on one tile of one sample, so a wave's atomic adds fall into two cache lines instead of eight
     uint32_t tiles_w;            // ceil(width / 8)

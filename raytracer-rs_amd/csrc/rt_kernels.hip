@@ -472,7 +472,35 @@ struct ShadeResult {
     uint32_t vis_pk = 0, vis_nk = 0;
 };
 
-template <int SHADER, class SC>
+// Russian roulette (RT_FLAG_RUSSIAN_ROULETTE; the reference has none, shader.rs:94-96 only stops at depth 40): a child at
+// depth >= RT_RR_MIN_DEPTH survives with probability q = the largest component of the material's attenuation (at least
+// 0.05, at most 1: mirrors and glass always survive) and carries its weight divided by q.  q depends on the material
+// alone and the draw on (pixel, sample, node, branch), so the recursive form makes the same decisions.
+__device__ __forceinline__ float roulette_q(const rt_material &m) {
+    const F3 a = mat_attenuation(m);
+    return fminf(1.0f, fmaxf(fmaxf(a.x, fmaxf(a.y, a.z)), 0.05f));
+}
+__device__ __forceinline__ bool roulette(const rt_material &m, uint32_t pk, uint32_t nk, uint32_t dim, uint32_t child_depth, F3 *w) {
+    if (child_depth < RT_RR_MIN_DEPTH) return true;
+    const float q = roulette_q(m);
+    Stream st(pk, nk, dim);
+    if (!(st.next_f32() < q)) return false;
+    *w = div_w(*w, q);
+    return true;
+}
+
+// Cosine-weighted scattering for Diffuse surfaces (RT_FLAG_COSINE_DIFFUSE; the reference samples the hemisphere
+// uniformly and calls the density 1/pi, material.rs:85-103,144-151): direction = normalize(n + point on the unit
+// sphere), density cos/pi, and the cosine enters the weight of the scattered ray.
+__device__ __forceinline__ F3 cosine_scatter(F3 n, uint32_t pk, uint32_t nk) {
+    Stream st(pk, nk, P_SCATTER);
+    const F3 nn = normalize(n);
+    const F3 d = nn + unit_vec_on_sphere(st);
+    return dot(d, d) < 1e-12f ? nn : normalize(d);
+}
+__device__ __forceinline__ float cosine_of(F3 d, F3 n) { return fmaxf(dot(normalize(d), normalize(n)), 0.0f); }
+
+template <int SHADER, bool EXT, class SC>
 __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, float *planes, uint32_t n_pixels, const Node &nd, float2 h,
                                            ShadeResult &r) {
     const float t_obj = h.x;
@@ -502,14 +530,25 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
         surface_at(sc, code, p, &n, &mat_id);
         const rt_material m = sc.mats[mat_id];
         const uint32_t pk = pixel_key(rc.seed, pixel);
+        const bool rr = EXT && (rc.flags & RT_FLAG_RUSSIAN_ROULETTE) != 0u;
+        const bool cosine = EXT && (rc.flags & RT_FLAG_COSINE_DIFFUSE) != 0u && m.kind == RT_MAT_DIFFUSE;
 
         if (SHADER == RT_SHADER_MIS) {
             F3 sd;
-            if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+            bool scat;
+            if (cosine) { sd = cosine_scatter(n, pk, nd.nk); scat = true; }
+            else scat = mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd);
+            if (scat) {
                 F3 brdf;
                 float pdf;
                 mat_brdf_pdf(m, nd.d, sd, n, rc.t_min, &brdf, &pdf);
+                if (cosine) {
+                    const float c = cosine_of(sd, n);
+                    brdf = brdf * c;
+                    pdf = c * (1.0f / RTD_PI);
+                }
                 F3 w = mul_v(beta, brdf);
+                if (rr && !roulette(m, pk, nd.nk, P_ROULETTE, depth + 1u, &w)) w = f3(0.0f, 0.0f, 0.0f);
                 if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have0 = true;
                     r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = pdf;
@@ -527,6 +566,7 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 F3 w = mul_v(beta, mul_v(kd, albedo_of(m) * (1.0f / RTD_PI)));
                 uint32_t dmin = (uint32_t)max(rc.max_depth - 6, 0); // depth.max(34) for the reference's 40
                 uint32_t d1 = max(depth, dmin) + 1u;
+                if (rr && !roulette(m, pk, nd.nk, P_ROULETTE1, d1, &w)) w = f3(0.0f, 0.0f, 0.0f);
                 if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have1 = true;
                     r.c1.o = p; r.c1.d = dd; r.c1.w = w; r.c1.b_pdf = 1.0f / RTD_PI;
@@ -540,6 +580,7 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 F3 brdf;
                 float pdf;
                 mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
+                if (cosine) pdf = cosine_of(ldir, n) * (1.0f / RTD_PI);
                 F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
                 F3 c = mul_v(beta, direct);
                 if (!is_black(c)) {
@@ -549,8 +590,12 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
             }
         } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
             F3 sd;
-            if (mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd)) {
+            bool scat;
+            if (cosine) { sd = cosine_scatter(n, pk, nd.nk); scat = true; } // weight albedo/pi * cos / (cos/pi) = the attenuation
+            else scat = mat_scatter_d(m, nd.d, n, rc.t_min, pk, nd.nk, &sd);
+            if (scat) {
                 F3 w = mul_v(beta, mat_attenuation(m));
+                if (rr && !roulette(m, pk, nd.nk, P_ROULETTE, depth + 1u, &w)) w = f3(0.0f, 0.0f, 0.0f);
                 if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have0 = true;
                     r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = 1.0f;
@@ -654,7 +699,7 @@ __device__ __forceinline__ ShadeScene stage_tables(const DevScene &sc, ShadeTabl
     return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.n_light, sc.n_sph, sc.n_cyl};
 }
 
-template <int SHADER, bool LDS_TABLES>
+template <int SHADER, bool LDS_TABLES, bool EXT = false>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
@@ -675,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     bool answered = false; // a light occlusion query answered in place, see below
     bool s_heavy = false;  // the occlusion query's ray touches the box of a big mesh
     auto shade = [&](const auto &view) {
-        if (il < n_seg) shade_node<SHADER>(view, rc, planes, n_pixels, nd_early, h_early, r);
+        if (il < n_seg) shade_node<SHADER, EXT>(view, rc, planes, n_pixels, nd_early, h_early, r);
         s_heavy = SHADER != RT_SHADER_WHITTED && r.have_s && ray_is_heavy(sc, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min);
         // A light occlusion query is a scan of the few loose triangles (and the spheres and cylinders): answered here, it
         // costs neither the 40-byte store, nor the occlusion kernel's 40-byte load, nor a slot in the shadow queue.
@@ -866,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
 // bounce.  Second children (Microfacet: they start at depth >= max_depth - 5, so at most six are ever pending) wait on
 // a small stack of the thread; should it overflow they go to the next queue, which a further launch of this kernel
 // takes up.  Same random numbers, same arithmetic as the staged kernels; only the order of the atomic adds differs.
-template <int SHADER>
+template <int SHADER, bool EXT = false>
 __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, float *planes, uint32_t n_pixels,
                                                 uint32_t seg_capacity, uint32_t heavy_blocks) {
     uint32_t seg, bx;
@@ -886,7 +931,7 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl
         // (the plain walk: with the top of the tree in LDS and the scan of the loose triangles this kernel was measured no faster)
         world_hit<false>(sc, nullptr, nd.o, nd.d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
         ShadeResult r;
-        shade_node<SHADER>(sc, rc, planes, n_pixels, nd, make_float2(t_obj, __int_as_float(code)), r);
+        shade_node<SHADER, EXT>(sc, rc, planes, n_pixels, nd, make_float2(t_obj, __int_as_float(code)), r);
         if (r.have_s) {
             shadows++;
             if (!world_occluded<false>(sc, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
@@ -1029,7 +1074,12 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
     const bool tab = tables_fit(sc);
-    if (shader == RT_SHADER_MIS && tab)
+    const bool ext = (rc.flags & (RT_FLAG_RUSSIAN_ROULETTE | RT_FLAG_COSINE_DIFFUSE)) != 0u; // options the reference does not have: own instantiations
+    if (ext && shader == RT_SHADER_MIS)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, false, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (ext && shader == RT_SHADER_PATH)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, false, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (shader == RT_SHADER_MIS && tab)
         hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else if (shader == RT_SHADER_PATH && tab)
         hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
@@ -1061,7 +1111,10 @@ void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const Ren
     const uint32_t grid = class_grid(light_threads, heavy_threads, &hb);
     if (!grid) return;
     dim3 g(grid), b(BLOCK);
-    if (shader == RT_SHADER_MIS) hipLaunchKernelGGL(k_tail<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
+    const bool ext = (rc.flags & (RT_FLAG_RUSSIAN_ROULETTE | RT_FLAG_COSINE_DIFFUSE)) != 0u;
+    if (ext && shader == RT_SHADER_MIS) hipLaunchKernelGGL((k_tail<RT_SHADER_MIS, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
+    else if (ext) hipLaunchKernelGGL((k_tail<RT_SHADER_PATH, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
+    else if (shader == RT_SHADER_MIS) hipLaunchKernelGGL(k_tail<RT_SHADER_MIS>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
     else hipLaunchKernelGGL(k_tail<RT_SHADER_PATH>, g, b, 0, cfg.stream, sc, rc, ctl, in, out, planes, n_pixels, cfg.seg_capacity, hb);
 }
 

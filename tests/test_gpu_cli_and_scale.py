@@ -76,6 +76,23 @@ def test_rtcli_resumes_a_stopped_render(tmp_path):
     assert r.returncode == 1 and "another frame size, sample count or seed" in r.stderr
 
 
+def test_rtcli_png_and_enlarged_output(tmp_path):
+    """The chessboard comparison images of the reference are 200x200 Whitted renders enlarged 8x by pixel repetition
+    (resize.py:5-11) and converted to an 8-bit format: `--upscale 8 --out x.png` does both."""
+    from PIL import Image
+
+    small, big = tmp_path / "s.ppm", tmp_path / "b.png"
+    common = (2, "--scene", "blue_noise_test", "--width", 40, "--height", 40, "--spp", 4, "--shader", "whitted", "--pixel-sampler", 2)
+    assert run_cli(*common, "--out", small).returncode == 0
+    r = run_cli(*common, "--out", big, "--upscale", 8)
+    assert r.returncode == 0, r.stderr
+    s = read_ppm(small)
+    b = np.asarray(Image.open(big).convert("RGB"), np.int64)
+    assert b.shape == (320, 320, 3)
+    want = np.clip(np.repeat(np.repeat(s, 8, axis=0), 8, axis=1), 0, 255)
+    assert np.abs(b - want).max() <= 1 and (b != want).mean() < 0.01  # two renders: the atomic adds may round differently
+
+
 def test_full_size_composite_4k(rt, orc, gpu_ctx):
     """The largest benchmark frame (3840x2160, composite scene, 68 K triangles) at 16 of its 4096 samples: primary ids
     and distances bit-exact against the oracle, sample ranges add up, ray counts are a function of the inputs, the

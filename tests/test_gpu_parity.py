@@ -71,6 +71,13 @@ SWEEP = [
     ("blue_noise_test", 48, 48, 4, {"shader": 2}),
     ("cornell", 32, 32, 2, {"shader": 2}),
     ("cornell", 32, 32, 2, {"shader": 0}),
+    # options beyond the reference: Russian roulette (4), cosine-weighted Diffuse scattering (8); the oracle implements both
+    ("head", 48, 48, 6, {"flags": 4}),
+    ("head", 48, 48, 6, {"flags": 8}),
+    ("utah", 64, 36, 4, {"flags": 12}),
+    ("cornell", 40, 40, 4, {"flags": 12, "seed": 5}),
+    ("whitted", 40, 40, 4, {"shader": 2, "flags": 12}),
+    ("mis_test", 48, 32, 4, {"flags": 12, "max_depth": 5}),
 ]
 
 
@@ -189,6 +196,25 @@ def test_scan_of_loose_triangles_matches_the_walk(rt, orc, gpu_ctx, monkeypatch,
     ca, cs = osc.render(hs.camera, p)
     assert_radiance_close(ga, ca)
     assert gs.camera_samples == W * H * spp
+    ds.close()
+
+
+def test_roulette_keeps_the_mean_and_shortens_paths(rt, gpu_ctx, monkeypatch):
+    """RT_FLAG_RUSSIAN_ROULETTE: same expectation as the reference's estimator (which only stops at depth 40,
+    src/shader.rs:94-96) with a fraction of the rays; identical with and without the tail kernel."""
+    hs = rt.HostScene("head", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    spp = 256
+    a, sa = ds.render(hs.camera, rt.default_params(64, 64, spp))
+    b, sb = ds.render(hs.camera, rt.default_params(64, 64, spp, flags=rt.FLAG_RUSSIAN_ROULETTE))
+    fin = np.isfinite(a).all(axis=2) & np.isfinite(b).all(axis=2)
+    ma, mb = a[fin].mean(axis=0) / spp, b[fin].mean(axis=0) / spp
+    assert np.abs(mb - ma).max() < 0.01 * ma.max(), (ma, mb)
+    assert sb.rays_closest < 0.6 * sa.rays_closest and sb.iterations < sa.iterations
+    monkeypatch.setenv("RT_TAIL", "0")
+    c, sc_ = ds.render(hs.camera, rt.default_params(64, 64, spp, flags=rt.FLAG_RUSSIAN_ROULETTE))
+    assert (sc_.rays_closest, sc_.rays_shadow) == (sb.rays_closest, sb.rays_shadow)
+    assert_radiance_close(c, b, rel=1e-5)
     ds.close()
 
 

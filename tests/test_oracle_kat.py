@@ -265,3 +265,25 @@ def test_unsupported_combinations_are_errors(orc, rt):
         assert e.value.code == rt.RT_ERR_UNSUPPORTED
     with pytest.raises(rt.RtError, match="unexpected integer"):
         osc.render(hs.camera, rt.default_params(8, 8, 1, pixel_sampler=9))
+
+
+def test_options_beyond_the_reference_are_off_by_default_and_behave_as_documented(orc, rt):
+    """RT_FLAG_RUSSIAN_ROULETTE keeps the expectation of the reference's estimator (src/shader.rs:93-115 stops only at
+    depth 40) with far fewer rays; RT_FLAG_COSINE_DIFFUSE changes it (density cos/pi instead of the nominal 1/pi of
+    src/material.rs:98-103).  Both are extensions: flags = 0 is what the golden renders pin."""
+    hs = rt.HostScene("head", 1.0)
+    osc = orc.OracleScene(hs.desc, 1)
+    spp = 128
+    out = {}
+    for name, flags in (("ref", 0), ("rr", rt.FLAG_RUSSIAN_ROULETTE), ("cos", rt.FLAG_COSINE_DIFFUSE)):
+        a, st = osc.render(hs.camera, rt.default_params(32, 32, spp, flags=flags))
+        fin = np.isfinite(a).all(axis=2)
+        out[name] = (a[fin].mean(axis=0) / spp, st)
+    ref, rr, cos = out["ref"], out["rr"], out["cos"]
+    assert np.abs(rr[0] - ref[0]).max() < 0.01 * ref[0].max()
+    assert rr[1].rays_closest < 0.5 * ref[1].rays_closest
+    assert np.abs(cos[0] - ref[0]).max() > 0.02 * ref[0].max()
+    # below RT_RR_MIN_DEPTH nothing changes: with max_depth = 2 no scattered ray is deep enough for roulette
+    a, _ = osc.render(hs.camera, rt.default_params(32, 32, 4, max_depth=rt.RR_MIN_DEPTH - 1))
+    b, _ = osc.render(hs.camera, rt.default_params(32, 32, 4, max_depth=rt.RR_MIN_DEPTH - 1, flags=rt.FLAG_RUSSIAN_ROULETTE))
+    assert np.array_equal(a, b, equal_nan=True)

@@ -92,7 +92,7 @@ struct rt_context {
 
 struct rt_scene {
     rt_context *ctx = nullptr;
-    DevBuf<float4> nodes, tris, sph, loose;
+    DevBuf<float4> nodes, tris, tri_nrm, sph, loose;
     DevBuf<uint4> cnodes;
     DevBuf<int2> sph_info, cyl_info;
     DevBuf<int32_t> tri_of_prim;
@@ -555,6 +555,16 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     }
     for (int a = 0; a < 3; a++) { s->dev.q_lo[a] = bvh.q_lo[a]; s->dev.q_scale[a] = bvh.q_scale[a]; }
     s->dev.cnodes = s->cnodes.p;
+    {
+        hipError_t e = s->tri_nrm.ensure((size_t)std::max(d->n_tri, 1));
+        if (e == hipSuccess) {
+            launch_tri_normals(ctx->stream, s->tris.p, d->n_tri, s->tri_nrm.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return cleanup_fail(e, "triangle normals");
+        s->dev.tri_nrm = s->tri_nrm.p;
+    }
     s->info.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     s->info.bvh_on_device = on_device ? 1 : 0;
     s->info.n_nodes = bvh.n_nodes; s->info.n_orders = bvh.n_orders; s->info.n_top = bvh.n_top; s->info.n_triangles = d->n_tri;
@@ -688,7 +698,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     s->nodes.release(); s->cnodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
-    s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
+    s->tri_nrm.release(); s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
     delete s;
     return RT_OK;
 }

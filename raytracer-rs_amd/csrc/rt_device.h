@@ -124,6 +124,7 @@ struct DevScene {
     float q_lo[3], q_scale[3];
     const float4 *nodes;
     const float4 *tris;
+    const float4 *tri_nrm;      // per triangle record: unit geometric normal, material id (bits) in w
     const float4 *sph;      // cx cy cz r
     const int2 *sph_info;   // material, prim id
     const float *cyl;       // 5 floats: cx cz ymin ymax r

@@ -95,6 +95,7 @@ void launch_tail(const LaunchCfg &cfg, int shader, const DevScene &sc, const Ren
 void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, float *planes, uint32_t n_pixels);
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t);
 void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const float *planes, float *accum_rgb, uint32_t n_pixels);
+void launch_tri_normals(hipStream_t stream, const float4 *tris, int n, float4 *out);
 void launch_resolve(hipStream_t stream, const float *accum_rgb, int64_t n_pixels, int32_t spp, uint8_t *rgb8);
 
 } // namespace rtd

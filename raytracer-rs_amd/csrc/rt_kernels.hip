@@ -382,9 +382,9 @@ __device__ __forceinline__ void surface_at(const SC &sc, int code, F3 p, F3 *n, 
     int idx = hit_index(code);
     switch (hit_kind(code)) {
     case HIT_KIND_TRI: {
-        float4 b = sc.tris[3 * idx + 1], c = sc.tris[3 * idx + 2];
-        *n = normalize(cross(f3(b.x, b.y, b.z), f3(c.x, c.y, c.z))); // geometry.rs:59
-        *mat = __float_as_int(b.w);
+        const float4 nm = sc.tri_nrm[idx]; // normalize(E1 x E2) (geometry.rs:59) and the material, from k_tri_normals
+        *n = f3(nm.x, nm.y, nm.z);
+        *mat = __float_as_int(nm.w);
         break;
     }
     case HIT_KIND_SPH: {
@@ -677,6 +677,7 @@ struct ShadeScene {
     const float *cyl;
     const int2 *cyl_info;
     const float4 *tris;
+    const float4 *tri_nrm;
     int32_t n_light, n_sph, n_cyl;
     __device__ __forceinline__ operator const DevScene &() const { return g; }
 };
@@ -696,7 +697,7 @@ __device__ __forceinline__ ShadeScene stage_tables(const DevScene &sc, ShadeTabl
     copy(tb.cyl, sc.cyl, (uint32_t)sc.n_cyl * 20u);
     copy(tb.cyl_info, sc.cyl_info, (uint32_t)sc.n_cyl * 8u);
     __syncthreads();
-    return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.n_light, sc.n_sph, sc.n_cyl};
+    return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.tri_nrm, sc.n_light, sc.n_sph, sc.n_cyl};
 }
 
 template <int SHADER, bool LDS_TABLES, bool EXT = false>
@@ -954,6 +955,17 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl
     if (shadows) atomicAdd(&ctl->h.rays_shadow, (unsigned long long)shadows);
 }
 
+// One record per triangle for the shading kernel: the geometric normal of geometry.rs:59 and the material id, so that
+// a shaded hit costs one 16-byte load instead of two and no cross product, square root and division.  Computed here,
+// by the arithmetic the shading code used to run per hit, once per scene.
+__global__ __launch_bounds__(BLOCK) void k_tri_normals(const float4 *tris, int n, float4 *out) {
+    const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
+    if (i >= n) return;
+    const float4 b = tris[3 * (size_t)i + 1], c = tris[3 * (size_t)i + 2];
+    const F3 nm = normalize(cross(f3(b.x, b.y, b.z), f3(c.x, c.y, c.z)));
+    out[i] = make_float4(nm.x, nm.y, nm.z, b.w);
+}
+
 // ---- normal shader (shader.rs:7-13): no queues, one thread per pixel looping over its samples ---------------------------
 __global__ __launch_bounds__(BLOCK) void k_normal_shader(DevScene sc, RenderConst rc, float *planes, uint32_t n_pixels) {
     const uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x;
@@ -1129,6 +1141,10 @@ void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderC
 
 void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const float *planes, float *accum_rgb, uint32_t n_pixels) {
     hipLaunchKernelGGL(k_planes_to_rgb, dim3(nblocks(n_pixels)), dim3(BLOCK), 0, cfg.stream, rc, planes, accum_rgb, n_pixels);
+}
+
+void launch_tri_normals(hipStream_t stream, const float4 *tris, int n, float4 *out) {
+    if (n > 0) hipLaunchKernelGGL(k_tri_normals, dim3(nblocks((uint32_t)n)), dim3(BLOCK), 0, stream, tris, n, out);
 }
 
 void launch_resolve(hipStream_t stream, const float *accum_rgb, int64_t n_pixels, int32_t spp, uint8_t *rgb8) {

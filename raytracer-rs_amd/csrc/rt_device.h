@@ -41,6 +41,10 @@ __device__ __forceinline__ bool all_finite(F3 a) { return isfinite(a.x) && isfin
 // a 1-ulp error to 1e-3; a 1-ulp error in a final quotient stays 1 ulp.
 __device__ __forceinline__ float rcp_w(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float div_w(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rsq_w(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sqrt_w(float x) { return __builtin_amdgcn_sqrtf(x); }
+// cosine between two vectors as a final factor of a path's weight (next-event estimation): no cancellation follows it
+__device__ __forceinline__ float cos_w(F3 a, F3 b) { return dot(a, b) * (rsq_w(dot(a, a)) * rsq_w(dot(b, b))); }
 __device__ __forceinline__ F3 div_w(F3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return F3{a.x * r, a.y * r, a.z * r}; }
 
 #define RTD_PI 3.14159265358979323846f
@@ -721,6 +725,20 @@ __device__ __forceinline__ bool light_mesh_hit(const SC &sc, const DevLight &L, 
     return any;
 }
 
+// The same for a ray aimed at a point sampled on face `tri` of the light (PolygonLight::pdf inside visible_d,
+// light.rs:328,334-342).  The light is planar, so any other face the ray meets is met at the same point of that plane,
+// on the edge it shares with `tri`, at a distance that differs in the last bits at most: the sampled face alone gives
+// the distance, and the loop over all faces runs only when rounding puts the sample outside its own face.
+template <class SC>
+__device__ __forceinline__ bool light_mesh_hit_sampled(const SC &sc, const DevLight &L, int tri, F3 o, F3 d, float t_min, float t_max, float *t_out) {
+    const F3 v0 = ltri_vertex(sc, tri, 0);
+    const F3 E1 = ltri_vertex(sc, tri, 1) - v0;
+    const F3 E2 = ltri_vertex(sc, tri, 2) - v0;
+    float t;
+    if (tri_hit(v0, E1, E2, o, d, t_min, t_max, true, &t)) { *t_out = t; return true; }
+    return light_mesh_hit(sc, L, o, d, t_min, t_max, t_out);
+}
+
 // Light::hit: light.rs:101-103, 223-238, 344-346
 template <class SC>
 __device__ __forceinline__ bool light_hit(const SC &sc, const DevLight &L, F3 o, F3 d, float t_min, float t_max, float *t_out) {
@@ -882,7 +900,7 @@ __device__ __forceinline__ float ggx_schlick(float nov, float k) { return div_w(
 __device__ __forceinline__ float ggx_partial_geometry_term(F3 l, F3 v, F3 n, float alpha) {
     float nol = fabsf(dot(n, l));
     float nov = fabsf(dot(n, v));
-    float r = sqrtf(alpha);
+    float r = sqrt_w(alpha);
     float k = ((r + 1.0f) * (r + 1.0f)) * 0.125f;
     return ggx_schlick(nol, k) * ggx_schlick(nov, k);
 }

@@ -431,7 +431,7 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
     if (L.kind == RT_LIGHT_POINT) {
         F3 dir = f3(L.ox, L.oy, L.oz) - p;
         *dir_out = dir;
-        *radiance = div_w(spectrum * dot(normalize(dir), normalize(n)), dot(dir, dir)); // light.rs:79
+        *radiance = div_w(spectrum * cos_w(dir, n), dot(dir, dir)); // light.rs:79
         *p_light = RTD_ZERO;
         return true;
     }
@@ -440,7 +440,7 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
         if (!disk_sample_d(L.sampler_kind, L.radius, rc.light_samples, rc.ns2_edge, st, &a, &b)) return false;
         F3 origin = f3(L.ox, L.oy, L.oz) + f3(a - L.radius, 0.0f, b - L.radius);
         F3 dir = origin - p;
-        float cs = dot(normalize(dir), normalize(n));
+        float cs = cos_w(dir, n);
         *dir_out = dir;
         *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
         *p_light = disk_pdf(L, dir, dot(dir, dir));
@@ -450,11 +450,11 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
     int tri = L.tri_first + (int)st.next_index((uint32_t)L.tri_count);
     F3 origin = sample_in_triangle(sc, tri, st);
     F3 dir = origin - p;
-    float cs = dot(normalize(dir), normalize(n));
+    float cs = cos_w(dir, n);
     *dir_out = dir;
     *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
     float t_l;
-    bool h = light_mesh_hit(sc, L, p, dir, rc.t_min, rc.t_max, &t_l); // self.pdf(&r), light.rs:328,334-342
+    bool h = light_mesh_hit_sampled(sc, L, tri, p, dir, rc.t_min, rc.t_max, &t_l); // self.pdf(&r), light.rs:328,334-342
     *p_light = light_pdf_with_t(L, dir, h, t_l);
     return true;
 }

@@ -648,11 +648,12 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
             for (int i = 0; i < d->n_cyl; i++) { grow(std::fabs(d->cyl[5 * i]) + std::fabs(d->cyl[5 * i + 4])); grow(std::fabs(d->cyl[5 * i + 1]) + std::fabs(d->cyl[5 * i + 4])); grow(d->cyl[5 * i + 2]); grow(d->cyl[5 * i + 3]); }
             for (int i = 0; i < d->n_light; i++) for (int a = 0; a < 3; a++) grow(std::fabs(d->lights[i].origin[a]) + std::fabs(d->lights[i].radius));
             for (size_t i = 0; i < 9 * (size_t)d->n_light_tri; i++) grow(d->light_tri_v[i]);
+            std::vector<float> planes; // behind the triangle records, padded to a multiple of four (loose_traverse loads four at a time)
             for (const auto &pi : by_prim) {
                 const float *rec = &bvh.tris[12 * (size_t)pi.second];
                 loose.insert(loose.end(), rec, rec + 12);
                 std::memcpy(&loose[loose.size() - 1], &pi.second, sizeof(int32_t));
-                // Fourth word: the triangle's plane, scaled so that "farther than 1" means "safely off the plane" — an
+                // The triangle's plane, scaled so that "farther than 1" means "safely off the plane" — an
                 // occlusion query whose segment starts behind it or ends in front of it by that margin cannot hit the
                 // front face, whatever the rounding of the exact test (loose_traverse).  Margin: 1e-4 of the scene's
                 // scale, more for slivers (the exact test's error grows with |E1||E2| / |E1 x E2|).
@@ -668,8 +669,11 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
                     plane[0] = (float)(nx * k); plane[1] = (float)(ny * k); plane[2] = (float)(nz * k);
                     plane[3] = (float)((nx * rec[0] + ny * rec[1] + nz * rec[2]) * k);
                 }
-                loose.insert(loose.end(), plane, plane + 4);
+                planes.insert(planes.end(), plane, plane + 4);
             }
+            const float nothing_in_front[4] = {0.0f, 0.0f, 0.0f, 2.0f}; // signed distance -2 for every point: always skipped
+            while ((planes.size() / 4) % 4 != 0) planes.insert(planes.end(), nothing_in_front, nothing_in_front + 4);
+            loose.insert(loose.end(), planes.begin(), planes.end());
         }
         UP(s->loose, loose.data(), loose.size() / 4, float4);
         s->dev.loose = s->loose.p;

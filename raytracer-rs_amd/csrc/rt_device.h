@@ -628,22 +628,8 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
 template <bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_tris) {
     TriHit best{t_max, -1, -1};
-    // An occlusion query over the segment t in [t_min, t_max] within [0, 1] can only hit a FRONT face whose plane the
-    // segment crosses from front to back: with the start behind the plane, or the end in front of it, by the margin the
-    // host scaled the plane with (1e-4 of the scene's size, more for slivers: far above the rounding of the exact test,
-    // so the exact test would reject as well), the triangle is skipped — and when that holds for every lane of the wave
-    // the exact test (50 instructions with its division) is not run at all.  In a closed room that is almost every
-    // triangle for almost every wave.  NaN coordinates compare false: never skipped.
-    const bool may_skip = ANY_HIT && t_min >= 0.0f && t_max <= 1.0f;
-    for (int k = 0; k < sc.n_loose; k++) {
-        if (may_skip) {
-            const float4 pl = sc.loose[4 * k + 3];
-            const float da = __builtin_fmaf(pl.x, o.x, __builtin_fmaf(pl.y, o.y, __builtin_fmaf(pl.z, o.z, -pl.w)));
-            const float db = da + __builtin_fmaf(pl.x, d.x, __builtin_fmaf(pl.y, d.y, pl.z * d.z));
-            const bool off = da <= -1.0f || db >= 1.0f;
-            if (__ballot(!off) == 0ull) continue;
-        }
-        const float4 a = sc.loose[4 * k], b = sc.loose[4 * k + 1], c = sc.loose[4 * k + 2];
+    auto test = [&](int k) { // exact test of loose triangle k; true = an occlusion query is answered
+        const float4 a = sc.loose[3 * k], b = sc.loose[3 * k + 1], c = sc.loose[3 * k + 2];
         if (COUNT) (*n_tris)++;
         float t;
         if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
@@ -651,8 +637,39 @@ __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d,
             if (ANY_HIT || t < best.t || (t == best.t && prim > best.prim)) {
                 best.t = t; best.tri = __float_as_int(c.w); best.prim = prim;
             }
-            if (ANY_HIT) break;
+            return ANY_HIT;
         }
+        return false;
+    };
+    // An occlusion query over the segment t in [t_min, t_max] within [0, 1] can only hit a FRONT face whose plane the
+    // segment crosses from front to back: with the start behind the plane, or the end in front of it, by the margin the
+    // host scaled the plane with (1e-4 of the scene's size, more for slivers: far above the rounding of the exact test,
+    // so the exact test would reject as well), the triangle is skipped — and when that holds for every lane of the wave
+    // the exact test (50 instructions with its division) is not run at all.  In a closed room that is almost every
+    // triangle for almost every wave.  NaN coordinates compare false: never skipped.  The planes lie behind the triangle
+    // records, padded to a multiple of four with planes nothing is in front of: four planes come with one scalar load,
+    // so a wave waits for memory once per four triangles instead of once per triangle.
+    if (ANY_HIT && t_min >= 0.0f && t_max <= 1.0f) {
+        const float4 *planes = sc.loose + 3 * sc.n_loose;
+        bool found = false;
+        for (int k0 = 0; k0 < sc.n_loose; k0 += 4) {
+            const float4 p0 = planes[k0], p1 = planes[k0 + 1], p2 = planes[k0 + 2], p3 = planes[k0 + 3];
+            auto crosses = [&](const float4 &pl) {
+                const float da = __builtin_fmaf(pl.x, o.x, __builtin_fmaf(pl.y, o.y, __builtin_fmaf(pl.z, o.z, -pl.w)));
+                const float db = da + __builtin_fmaf(pl.x, d.x, __builtin_fmaf(pl.y, d.y, pl.z * d.z));
+                return !found && !(da <= -1.0f || db >= 1.0f);
+            };
+            const bool c0 = crosses(p0), c1 = crosses(p1), c2 = crosses(p2), c3 = crosses(p3);
+            if (__ballot(c0) != 0ull && !found) found = test(k0);
+            if (__ballot(c1) != 0ull && !found) found = test(k0 + 1);
+            if (__ballot(c2) != 0ull && !found) found = test(k0 + 2);
+            if (__ballot(c3) != 0ull && !found) found = test(k0 + 3);
+            if (__ballot(!found) == 0ull) break;
+        }
+        return best;
+    }
+    for (int k = 0; k < sc.n_loose; k++) {
+        if (test(k)) break;
     }
     return best;
 }

@@ -87,8 +87,11 @@ struct BlockAppendSeg {
 };
 
 // `answered` = this lane's occlusion query was answered in place (counted for the statistics, no slot)
+// `meanwhile` runs between the issue of the workgroup's reserving atomics and the first use of what they return: work
+// that does not depend on the slots hides their round trip through the memory side.
+template <class F>
 __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const bool (&heavy)[3], bool answered,
-                                                 uint32_t seg_l, uint32_t (&slot)[3]) {
+                                                 uint32_t seg_l, uint32_t (&slot)[3], F &&meanwhile) {
     const uint32_t lane = threadIdx.x & 63u;
     if (threadIdx.x < 5u) sm.cnt[threadIdx.x] = 0u;
     const uint32_t n_answered = (uint32_t)__popcll(__ballot(answered));
@@ -109,12 +112,15 @@ __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, c
     }
     __syncthreads();
     if (threadIdx.x == 4u && sm.cnt[4] != 0u) atomicAdd(&ctl->seg_inline[seg_l].v, sm.cnt[4]);
+    uint32_t reserved = 0u;
     if (threadIdx.x < 4u) {
         const uint32_t c = sm.cnt[threadIdx.x];
         uint32_t *counter = threadIdx.x == 0u ? &ctl->seg_out[seg_l].v : threadIdx.x == 1u ? &ctl->seg_out[RT_NSEG_HALF + seg_l].v
                           : threadIdx.x == 2u ? &ctl->seg_shadow[seg_l].v : &ctl->seg_shadow[RT_NSEG_HALF + seg_l].v;
-        sm.base[threadIdx.x] = c ? atomicAdd(counter, c) : 0u;
+        if (c) reserved = atomicAdd(counter, c);
     }
+    meanwhile();
+    if (threadIdx.x < 4u) sm.base[threadIdx.x] = reserved;
     __syncthreads();
     const uint32_t b0 = sm.base[0] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 0);
     const uint32_t b1 = sm.base[1] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 1);
@@ -720,19 +726,29 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     ShadeResult r;
     bool answered = false; // a light occlusion query answered in place, see below
     bool s_heavy = false;  // the occlusion query's ray touches the box of a big mesh
+    bool heavy0 = false, heavy1 = false;
+    uint32_t slot[3];
     auto shade = [&](const auto &view) {
         if (il < n_seg) shade_node<SHADER, EXT>(view, rc, planes, n_pixels, nd_early, h_early, r);
+        // ---- compaction: children into the next queue, shadow rays into the shadow queue, light and heavy rays apart
         s_heavy = SHADER != RT_SHADER_WHITTED && r.have_s && ray_is_heavy(sc, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min);
+        heavy0 = r.have0 && ray_is_heavy(sc, r.c0.o, r.c0.d, rc.t_min, rc.t_max);
+        heavy1 = r.have1 && ray_is_heavy(sc, r.c1.o, r.c1.d, rc.t_min, rc.t_max);
         // A light occlusion query is a scan of the few loose triangles (and the spheres and cylinders): answered here, it
         // costs neither the 40-byte store, nor the occlusion kernel's 40-byte load, nor a slot in the shadow queue.
-        if (SHADER != RT_SHADER_WHITTED && sc.inline_shadow && sc.n_loose >= 0) {
-            answered = r.have_s && !s_heavy;
-            if (__ballot(answered) != 0ull) {
+        const bool in_place = SHADER != RT_SHADER_WHITTED && sc.inline_shadow && sc.n_loose >= 0;
+        answered = in_place && r.have_s && !s_heavy;
+        const bool nee = SHADER != RT_SHADER_WHITTED && r.have_s;
+        const bool valid3[3] = {r.have0, r.have1, nee && !answered};
+        const bool heavy3[3] = {heavy0, heavy1, nee && s_heavy};
+        // the scan runs while the workgroup's slot reservations are on their way to the memory side and back
+        block_append_seg(sm, ctl, valid3, heavy3, answered, oseg_l, slot, [&]() {
+            if (in_place && __ballot(answered) != 0ull) {
                 uint32_t nn = 0, nt = 0;
                 const bool occ = answered && world_occluded<false, false, true>(view, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
                 if (answered && !occ) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
             }
-        }
+        });
     };
     if constexpr (LDS_TABLES) shade(stage_tables(sc, tb));
     else shade(sc);
@@ -740,18 +756,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     const Node &c0 = r.c0, &c1 = r.c1;
     const F3 s_o = r.s_o, s_d = r.s_d, s_c = r.s_c, vis_p = r.vis_p, vis_n = r.vis_n, vis_w = r.vis_w;
     const uint32_t s_pixel = r.s_pixel, vis_pk = r.vis_pk, vis_nk = r.vis_nk;
-
-    // ---- compaction: children into the next queue, shadow rays into the shadow queue, light and heavy rays apart
-    const bool heavy0 = have0 && ray_is_heavy(sc, c0.o, c0.d, rc.t_min, rc.t_max);
-    const bool heavy1 = have1 && ray_is_heavy(sc, c1.o, c1.d, rc.t_min, rc.t_max);
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
     const bool heavy_s = nee && s_heavy;
     const bool queued = nee && !answered;
-    const bool valid3[3] = {have0, have1, queued};
-    const bool heavy3[3] = {heavy0, heavy1, heavy_s};
     const uint32_t seg3[3] = {ray_segment(heavy0, oseg_l), ray_segment(heavy1, oseg_l), ray_segment(heavy_s, oseg_l)};
-    uint32_t slot[3];
-    block_append_seg(sm, ctl, valid3, heavy3, answered, oseg_l, slot);
     if (have0) {
         if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0); else ctl->h.overflow = 1;
     }

@@ -86,14 +86,14 @@ struct BlockAppendSeg {
     uint32_t base[4];
 };
 
-// `answered` = this lane's occlusion query was answered in place (counted for the statistics, no slot)
+// `answered` = this lane's occlusion query was answered in place (counted for the statistics, no slot).
+// The caller zeroes sm.cnt[0..4] and passes a __syncthreads() before the call; one call per kernel (sm is not reset).
 // `meanwhile` runs between the issue of the workgroup's reserving atomics and the first use of what they return: work
 // that does not depend on the slots hides their round trip through the memory side.
 template <class F>
 __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, const bool (&valid)[3], const bool (&heavy)[3], bool answered,
                                                  uint32_t seg_l, uint32_t (&slot)[3], F &&meanwhile) {
     const uint32_t lane = threadIdx.x & 63u;
-    if (threadIdx.x < 5u) sm.cnt[threadIdx.x] = 0u;
     const uint32_t n_answered = (uint32_t)__popcll(__ballot(answered));
     unsigned long long m[3][2];
 #pragma unroll
@@ -104,7 +104,6 @@ __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, c
     const uint32_t n00 = (uint32_t)__popcll(m[0][0]), n01 = (uint32_t)__popcll(m[0][1]);
     const uint32_t cnt0 = n00 + (uint32_t)__popcll(m[1][0]), cnt1 = n01 + (uint32_t)__popcll(m[1][1]);
     const uint32_t cnt2 = (uint32_t)__popcll(m[2][0]), cnt3 = (uint32_t)__popcll(m[2][1]);
-    __syncthreads();
     uint32_t wave_base = 0;
     if (lane < 5u) {
         const uint32_t c = lane == 0u ? cnt0 : lane == 1u ? cnt1 : lane == 2u ? cnt2 : lane == 3u ? cnt3 : n_answered;
@@ -130,7 +129,6 @@ __device__ __forceinline__ void block_append_seg(BlockAppendSeg &sm, Ctl *ctl, c
     slot[0] = heavy[0] ? b1 + below(m[0][1]) : b0 + below(m[0][0]);
     slot[1] = heavy[1] ? b1 + n01 + below(m[1][1]) : b0 + n00 + below(m[1][0]);
     slot[2] = heavy[2] ? b3 + below(m[2][1]) : b2 + below(m[2][0]);
-    __syncthreads(); // sm may be reused by the next call
 }
 
 // segment of its class a workgroup appends to (any choice is correct; spreading by workgroup keeps the counters apart)
@@ -687,21 +685,40 @@ struct ShadeScene {
     int32_t n_light, n_sph, n_cyl;
     __device__ __forceinline__ operator const DevScene &() const { return g; }
 };
-// every thread of the workgroup must call it
-__device__ __forceinline__ ShadeScene stage_tables(const DevScene &sc, ShadeTables &tb) {
-    auto copy = [&](void *dst, const void *src, uint32_t bytes) {
-        uint32_t *d = static_cast<uint32_t *>(dst);
-        const uint32_t *s = static_cast<const uint32_t *>(src);
-#pragma unroll 1
-        for (uint32_t i = threadIdx.x; i < bytes / 4u; i += BLOCK) d[i] = s[i];
-    };
-    copy(tb.lights, sc.lights, (uint32_t)sc.n_light * (uint32_t)sizeof(DevLight));
-    copy(tb.ltris, sc.ltris, (uint32_t)sc.n_light_tri * 36u);
-    copy(tb.mats, sc.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material));
-    copy(tb.sph, sc.sph, (uint32_t)sc.n_sph * 16u);
-    copy(tb.sph_info, sc.sph_info, (uint32_t)sc.n_sph * 8u);
-    copy(tb.cyl, sc.cyl, (uint32_t)sc.n_cyl * 20u);
-    copy(tb.cyl_info, sc.cyl_info, (uint32_t)sc.n_cyl * 8u);
+// Staging: stage_issue reads every thread's share of the tables into registers (at most 9 words: the table limits above
+// fit two rounds of BLOCK words for light triangles and materials, one for the rest), all loads in flight at once;
+// stage_commit writes them to LDS and synchronises.  Every thread of the workgroup must call both.  (Issuing the loads
+// before the workgroup knows whether it has any node to shade was measured slower: +3.6 % on the teapot frame.)
+struct StagedWords { uint32_t w[9]; };
+__device__ __forceinline__ StagedWords stage_issue(const DevScene &sc) {
+    static_assert(RT_TAB_LIGHTS * sizeof(DevLight) <= 4 * BLOCK && 36 * RT_TAB_LTRIS <= 8 * BLOCK && RT_TAB_MATS * sizeof(rt_material) <= 8 * BLOCK &&
+                  16 * RT_TAB_SPH <= 4 * BLOCK && 20 * RT_TAB_CYL <= 4 * BLOCK, "a thread stages at most two words per table");
+    const uint32_t t = threadIdx.x;
+    auto ld = [](const void *src, uint32_t bytes, uint32_t i) { return i < bytes / 4u ? static_cast<const uint32_t *>(src)[i] : 0u; };
+    StagedWords r;
+    r.w[0] = ld(sc.lights, (uint32_t)sc.n_light * (uint32_t)sizeof(DevLight), t);
+    r.w[1] = ld(sc.ltris, (uint32_t)sc.n_light_tri * 36u, t);
+    r.w[2] = ld(sc.ltris, (uint32_t)sc.n_light_tri * 36u, t + BLOCK);
+    r.w[3] = ld(sc.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material), t);
+    r.w[4] = ld(sc.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material), t + BLOCK);
+    r.w[5] = ld(sc.sph, (uint32_t)sc.n_sph * 16u, t);
+    r.w[6] = ld(sc.sph_info, (uint32_t)sc.n_sph * 8u, t);
+    r.w[7] = ld(sc.cyl, (uint32_t)sc.n_cyl * 20u, t);
+    r.w[8] = ld(sc.cyl_info, (uint32_t)sc.n_cyl * 8u, t);
+    return r;
+}
+__device__ __forceinline__ ShadeScene stage_commit(const DevScene &sc, ShadeTables &tb, const StagedWords &r) {
+    const uint32_t t = threadIdx.x;
+    auto st = [](void *dst, uint32_t bytes, uint32_t i, uint32_t v) { if (i < bytes / 4u) static_cast<uint32_t *>(dst)[i] = v; };
+    st(tb.lights, (uint32_t)sc.n_light * (uint32_t)sizeof(DevLight), t, r.w[0]);
+    st(tb.ltris, (uint32_t)sc.n_light_tri * 36u, t, r.w[1]);
+    st(tb.ltris, (uint32_t)sc.n_light_tri * 36u, t + BLOCK, r.w[2]);
+    st(tb.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material), t, r.w[3]);
+    st(tb.mats, (uint32_t)sc.n_mat * (uint32_t)sizeof(rt_material), t + BLOCK, r.w[4]);
+    st(tb.sph, (uint32_t)sc.n_sph * 16u, t, r.w[5]);
+    st(tb.sph_info, (uint32_t)sc.n_sph * 8u, t, r.w[6]);
+    st(tb.cyl, (uint32_t)sc.n_cyl * 20u, t, r.w[7]);
+    st(tb.cyl_info, (uint32_t)sc.n_cyl * 8u, t, r.w[8]);
     __syncthreads();
     return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.tri_nrm, sc.n_light, sc.n_sph, sc.n_cyl};
 }
@@ -722,6 +739,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
     if (bx * BLOCK >= n_seg) return;
     const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
     __shared__ typename std::conditional<LDS_TABLES, ShadeTables, char>::type tb;
+    if (threadIdx.x < 5u) sm.cnt[threadIdx.x] = 0u; // for block_append_seg; the barrier below (or stage_commit's) publishes it
 
     ShadeResult r;
     bool answered = false; // a light occlusion query answered in place, see below
@@ -750,8 +768,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ct
             }
         });
     };
-    if constexpr (LDS_TABLES) shade(stage_tables(sc, tb));
-    else shade(sc);
+    if constexpr (LDS_TABLES) shade(stage_commit(sc, tb, stage_issue(sc)));
+    else {
+        __syncthreads();
+        shade(sc);
+    }
     const bool have0 = r.have0, have1 = r.have1, have_s = r.have_s, vis_pending = r.vis_pending;
     const Node &c0 = r.c0, &c1 = r.c1;
     const F3 s_o = r.s_o, s_d = r.s_d, s_c = r.s_c, vis_p = r.vis_p, vis_n = r.vis_n, vis_w = r.vis_w;

@@ -532,7 +532,7 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
         F3 n;
         int mat_id;
         surface_at(sc, code, p, &n, &mat_id);
-        const rt_material m = sc.mats[mat_id];
+        const rt_material &m = sc.mats[mat_id]; // read where used (LDS when the tables are staged): a copy costs 10 registers for the whole function
         const uint32_t pk = pixel_key(rc.seed, pixel);
         const bool rr = EXT && (rc.flags & RT_FLAG_RUSSIAN_ROULETTE) != 0u;
         const bool cosine = EXT && (rc.flags & RT_FLAG_COSINE_DIFFUSE) != 0u && m.kind == RT_MAT_DIFFUSE;
@@ -723,8 +723,11 @@ __device__ __forceinline__ ShadeScene stage_commit(const DevScene &sc, ShadeTabl
     return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.tri_nrm, sc.n_light, sc.n_sph, sc.n_cyl};
 }
 
+// Five waves per SIMD (at most 96 registers; the kernel needs 92): the kernel waits on memory at its start (node,
+// tables), at the queue append and behind its atomic adds, and a fifth wave fills those gaps: -5 % per frame against
+// the four waves that 102 registers allowed.  Six waves (80 registers) spill: slower.
 template <int SHADER, bool LDS_TABLES, bool EXT = false>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     __shared__ BlockAppendSeg sm;

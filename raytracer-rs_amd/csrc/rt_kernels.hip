@@ -538,6 +538,22 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
         const bool cosine = EXT && (rc.flags & RT_FLAG_COSINE_DIFFUSE) != 0u && m.kind == RT_MAT_DIFFUSE;
 
         if (SHADER == RT_SHADER_MIS) {
+            // (next-event estimation first: see the register note at k_shade; the order does not matter to the results,
+            // every random number is a function of (pixel, sample, node, purpose))
+            F3 ldir, radiance;
+            float p_l;
+            if (nee_sample(sc, rc, p, n, pk, nd.nk, &ldir, &radiance, &p_l)) { // material.rs:441-447, 473-480
+                F3 brdf;
+                float pdf;
+                mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
+                if (cosine) pdf = cosine_of(ldir, n) * (1.0f / RTD_PI);
+                F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
+                F3 c = mul_v(beta, direct);
+                if (!is_black(c)) {
+                    r.have_s = true;
+                    r.s_o = p; r.s_d = ldir; r.s_c = c; r.s_pixel = tiled_index(rc, pixel);
+                }
+            }
             F3 sd;
             bool scat;
             if (cosine) { sd = cosine_scatter(n, pk, nd.nk); scat = true; }
@@ -576,20 +592,6 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                     r.c1.o = p; r.c1.d = dd; r.c1.w = w; r.c1.b_pdf = 1.0f / RTD_PI;
                     r.c1.meta = make_meta(pixel, d1, 0u);
                     r.c1.nk = child_node_key(nd.nk, 1u);
-                }
-            }
-            F3 ldir, radiance;
-            float p_l;
-            if (nee_sample(sc, rc, p, n, pk, nd.nk, &ldir, &radiance, &p_l)) { // material.rs:441-447, 473-480
-                F3 brdf;
-                float pdf;
-                mat_brdf_pdf(m, nd.d, ldir, n, rc.t_min, &brdf, &pdf);
-                if (cosine) pdf = cosine_of(ldir, n) * (1.0f / RTD_PI);
-                F3 direct = div_w(mul_v(radiance, brdf), p_l + pdf);
-                F3 c = mul_v(beta, direct);
-                if (!is_black(c)) {
-                    r.have_s = true;
-                    r.s_o = p; r.s_d = ldir; r.s_c = c; r.s_pixel = tiled_index(rc, pixel);
                 }
             }
         } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
@@ -723,11 +725,12 @@ __device__ __forceinline__ ShadeScene stage_commit(const DevScene &sc, ShadeTabl
     return ShadeScene{sc, tb.lights, tb.ltris, tb.mats, tb.sph, tb.sph_info, tb.cyl, tb.cyl_info, sc.tris, sc.tri_nrm, sc.n_light, sc.n_sph, sc.n_cyl};
 }
 
-// Five waves per SIMD (at most 96 registers; the kernel needs 92): the kernel waits on memory at its start (node,
-// tables), at the queue append and behind its atomic adds, and a fifth wave fills those gaps: -5 % per frame against
-// the four waves that 102 registers allowed.  Six waves (80 registers) spill: slower.
+// Six waves per SIMD (80 registers): the kernel waits on memory at its start (node, tables), at the queue append and
+// behind its atomic adds, and further waves fill those gaps: four waves (102 registers) -> five (material read by
+// reference instead of copied) -5 % per frame -> six (next-event estimation evaluated before the scattered rays, so
+// that its temporaries are not live together with both children) another -4 %.
 template <int SHADER, bool LDS_TABLES, bool EXT = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     __shared__ BlockAppendSeg sm;

@@ -655,7 +655,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
                 std::memcpy(&loose[loose.size() - 1], &pi.second, sizeof(int32_t));
                 // The triangle's plane, scaled so that "farther than 1" means "safely off the plane" — an
                 // occlusion query whose segment starts behind it or ends in front of it by that margin cannot hit the
-                // front face, whatever the rounding of the exact test (loose_traverse).  Margin: 1e-4 of the scene's
+                // front face, whatever the rounding of the exact test (loose_traverse).  Margin: 2e-5 of the scene's
                 // scale, more for slivers (the exact test's error grows with |E1||E2| / |E1 x E2|).
                 const double e1[3] = {rec[4], rec[5], rec[6]}, e2[3] = {rec[8], rec[9], rec[10]};
                 const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
@@ -664,7 +664,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
                 float plane[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // degenerate triangle: never "safely off" — the exact test decides
                 if (nl > 0.0 && scale > 0.0 && std::isfinite(nl) && std::isfinite(scale)) {
                     const double sliver = l1 * l2 / nl;
-                    const double margin = 1e-4 * scale * std::max(1.0, sliver / 10.0);
+                    const double margin = 2e-5 * scale * std::max(1.0, sliver / 10.0); // the exact test's own error: about 1.5e-6 * scale
                     const double k = 1.0 / (nl * margin);
                     plane[0] = (float)(nx * k); plane[1] = (float)(ny * k); plane[2] = (float)(nz * k);
                     plane[3] = (float)((nx * rec[0] + ny * rec[1] + nz * rec[2]) * k);

@@ -641,9 +641,9 @@ __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d,
         }
         return false;
     };
-    // An occlusion query over the segment t in [t_min, t_max] within [0, 1] can only hit a FRONT face whose plane the
-    // segment crosses from front to back: with the start behind the plane, or the end in front of it, by the margin the
-    // host scaled the plane with (1e-4 of the scene's size, more for slivers: far above the rounding of the exact test,
+    // An occlusion query over the segment t in [t_min, t_max] (within [0, 1]: bounded) can only hit a FRONT face whose plane
+    // the segment crosses from front to back: with the start behind the plane, or the end in front of it, by the margin the
+    // host scaled the plane with (2e-5 of the scene's size, more for slivers: far above the rounding of the exact test,
     // so the exact test would reject as well), the triangle is skipped — and when that holds for every lane of the wave
     // the exact test (50 instructions with its division) is not run at all.  In a closed room that is almost every
     // triangle for almost every wave.  NaN coordinates compare false: never skipped.  The planes lie behind the triangle
@@ -655,9 +655,11 @@ __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d,
         for (int k0 = 0; k0 < sc.n_loose; k0 += 4) {
             const float4 p0 = planes[k0], p1 = planes[k0 + 1], p2 = planes[k0 + 2], p3 = planes[k0 + 3];
             auto crosses = [&](const float4 &pl) {
+                // signed distances (in margins) of the segment's two ends, o + t_min d and o + t_max d: the light of the
+                // reference's room lies IN the ceiling's plane, and only the 1 - T_MIN of the far end keeps it in front
                 const float da = __builtin_fmaf(pl.x, o.x, __builtin_fmaf(pl.y, o.y, __builtin_fmaf(pl.z, o.z, -pl.w)));
-                const float db = da + __builtin_fmaf(pl.x, d.x, __builtin_fmaf(pl.y, d.y, pl.z * d.z));
-                return !found && !(da <= -1.0f || db >= 1.0f);
+                const float dn = __builtin_fmaf(pl.x, d.x, __builtin_fmaf(pl.y, d.y, pl.z * d.z));
+                return !found && !(__builtin_fmaf(t_min, dn, da) <= -1.0f || __builtin_fmaf(t_max, dn, da) >= 1.0f);
             };
             const bool c0 = crosses(p0), c1 = crosses(p1), c2 = crosses(p2), c3 = crosses(p3);
             if (__ballot(c0) != 0ull && !found) found = test(k0);

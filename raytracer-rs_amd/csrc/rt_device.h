@@ -38,13 +38,12 @@ __device__ __forceinline__ bool all_finite(F3 a) { return isfinite(a.x) && isfin
 // hints.  Anything that decides where a path goes (hit tests, hit points, normals, sampled directions) uses the IEEE
 // forms above, so paths stay bit-identical with the CPU evaluation.  Unit vectors keep the IEEE normalisation as well:
 // they feed cancelling expressions ((1 - |cos|)^2 in the Fresnel term, wi + wo in the half vector) that would amplify
-// a 1-ulp error to 1e-3; a 1-ulp error in a final quotient stays 1 ulp.
+// a 1-ulp error to 1e-3; a 1-ulp error in a final quotient stays 1 ulp.  The cosine of next-event estimation keeps the
+// IEEE normalisations too: at grazing angles its three products cancel, and only bit-identical inputs keep the result
+// of that cancellation identical (reciprocal square roots there: 4e-4 relative on surfaces a hair from a light).
 __device__ __forceinline__ float rcp_w(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float div_w(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float rsq_w(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sqrt_w(float x) { return __builtin_amdgcn_sqrtf(x); }
-// cosine between two vectors as a final factor of a path's weight (next-event estimation): no cancellation follows it
-__device__ __forceinline__ float cos_w(F3 a, F3 b) { return dot(a, b) * (rsq_w(dot(a, a)) * rsq_w(dot(b, b))); }
 __device__ __forceinline__ F3 div_w(F3 a, float s) { const float r = __builtin_amdgcn_rcpf(s); return F3{a.x * r, a.y * r, a.z * r}; }
 
 #define RTD_PI 3.14159265358979323846f

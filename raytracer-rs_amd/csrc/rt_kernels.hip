@@ -435,7 +435,7 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
     if (L.kind == RT_LIGHT_POINT) {
         F3 dir = f3(L.ox, L.oy, L.oz) - p;
         *dir_out = dir;
-        *radiance = div_w(spectrum * cos_w(dir, n), dot(dir, dir)); // light.rs:79
+        *radiance = div_w(spectrum * dot(normalize(dir), normalize(n)), dot(dir, dir)); // light.rs:79
         *p_light = RTD_ZERO;
         return true;
     }
@@ -444,7 +444,7 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
         if (!disk_sample_d(L.sampler_kind, L.radius, rc.light_samples, rc.ns2_edge, st, &a, &b)) return false;
         F3 origin = f3(L.ox, L.oy, L.oz) + f3(a - L.radius, 0.0f, b - L.radius);
         F3 dir = origin - p;
-        float cs = cos_w(dir, n);
+        float cs = dot(normalize(dir), normalize(n));
         *dir_out = dir;
         *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
         *p_light = disk_pdf(L, dir, dot(dir, dir));
@@ -454,7 +454,7 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
     int tri = L.tri_first + (int)st.next_index((uint32_t)L.tri_count);
     F3 origin = sample_in_triangle(sc, tri, st);
     F3 dir = origin - p;
-    float cs = cos_w(dir, n);
+    float cs = dot(normalize(dir), normalize(n));
     *dir_out = dir;
     *radiance = cs > 0.0f ? spectrum * cs : f3(0.0f, 0.0f, 0.0f);
     float t_l;
@@ -728,9 +728,10 @@ __device__ __forceinline__ ShadeScene stage_commit(const DevScene &sc, ShadeTabl
 // Six waves per SIMD (80 registers): the kernel waits on memory at its start (node, tables), at the queue append and
 // behind its atomic adds, and further waves fill those gaps: four waves (102 registers) -> five (material read by
 // reference instead of copied) -5 % per frame -> six (next-event estimation evaluated before the scattered rays, so
-// that its temporaries are not live together with both children) another -4 %.
+// that its temporaries are not live together with both children) another -4 %.  The Whitted variant, with its
+// loop over light samples, needs 86 registers: five waves.
 template <int SHADER, bool LDS_TABLES, bool EXT = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADER == RT_SHADER_WHITTED ? 5 : 6, SHADER == RT_SHADER_WHITTED ? 5 : 6))) void k_shade(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, NodeQueue out, const float2 *hit,
                                                  ShadowQueue sh, float *planes, uint32_t n_pixels, uint32_t seg_capacity,
                                                  uint32_t shadow_seg_capacity, uint32_t heavy_blocks) {
     __shared__ BlockAppendSeg sm;

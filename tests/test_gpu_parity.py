@@ -358,6 +358,61 @@ def test_occluders_next_to_the_ends_of_shadow_segments(rt, orc, gpu_ctx, shader_
     assert lit["lit"] > 0 and lit["dark"] < 0.05 * lit["lit"]
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_soups_of_few_triangles(rt, orc, gpu_ctx, seed):
+    """Random triangles (few enough to be scanned, not walked), among them slivers, nearly coplanar pairs and faces
+    a hair away from the lights: occlusion queries skip a triangle only when a whole wave is clearly off its plane,
+    closest hits are decided by the exact test (src/geometry.rs:29-55) with the later triangle winning ties."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 17))
+    tris = []
+    for k in range(n):
+        c = rng.uniform(-1.2, 1.2, 3) + np.array([0, 0, -2.5])
+        kind = k % 4
+        if kind == 0:    # ordinary
+            a, b = rng.normal(0, 0.7, 3), rng.normal(0, 0.7, 3)
+        elif kind == 1:  # sliver
+            a = rng.normal(0, 0.9, 3)
+            b = a * 0.5 + rng.normal(0, 1e-4, 3)
+        elif kind == 2:  # nearly coplanar with the previous one, shifted by a few ulps of the scene's size
+            prev = np.array(tris[-1]).reshape(3, 3)
+            tris.append(list((prev + rng.normal(0, 3e-7, (3, 3))).reshape(-1)))
+            continue
+        else:            # large face, either orientation
+            a, b = rng.normal(0, 2.0, 3), rng.normal(0, 2.0, 3)
+        tris.append(list(np.concatenate([c, c + a, c + b])))
+    floor = [[-3, -1.5, 1, 3, -1.5, 1, 3, -1.5, -6], [-3, -1.5, 1, 3, -1.5, -6, -3, -1.5, -6]]
+    tri_v = np.array(floor + tris, np.float32)
+    # one light a hair in front of a face of the soup, one in the open
+    t0 = tri_v[2].reshape(3, 3).astype(np.float64)
+    nrm = np.cross(t0[1] - t0[0], t0[2] - t0[0])
+    nrm /= max(np.linalg.norm(nrm), 1e-20)
+    near = t0.mean(axis=0) + nrm * 1e-4
+    lights = [rt.Light(rt.LIGHT_POINT, tuple(float(v) for v in near), 0, (5, 5, 5), 0, 0, 1),
+              rt.Light(rt.LIGHT_POINT, (0.3, 1.4, -0.5), 0, (9, 8, 7), 0, 0, 1)]
+    sc = rt.NumpyScene(tri_v=tri_v, tri_mat=[k % 2 for k in range(len(tri_v))], mats=[rt.diffuse(0.8, 0.7, 0.6), rt.diffuse(0.3, 0.5, 0.9)],
+                       lights=lights)
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    osc = orc.OracleScene(sc.desc, 0, sc)
+    cam = rt.camera_new((0, 0.2, 2), (0, -0.3, -2), (0, 1, 0), 90.0, 1.0)
+    for shader in (rt.SHADER_MIS, rt.SHADER_WHITTED):
+        p = rt.default_params(56, 56, 3, shader=shader, seed=seed)
+        gp, gt = ds.primary_hits(cam, p)
+        cp, ct = osc.primary_hits(cam, p)
+        assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+        ga, _ = ds.render(cam, p)
+        ca, _ = osc.render(cam, p)
+        # Whitted's unclamped cosine (light.rs:79) gives terms of both signs and a light a hair from a face terms of 1e6:
+        # a channel can be the small difference of large terms, and only the ORDER of the additions differs between
+        # the two sides.  So the bar is relative to the pixel's largest channel, not to each channel's own value.
+        assert np.array_equal(np.isfinite(ga), np.isfinite(ca))
+        fin = np.isfinite(ca).all(axis=2)
+        scale = np.maximum(np.abs(ca[fin]).max(axis=1, keepdims=True), FLOOR)
+        err = np.abs(ga[fin] - ca[fin]) / scale
+        assert err.max() <= REL, f"max rel err {err.max():.3g}"
+    ds.close()
+
+
 def test_axis_aligned_cube_is_intact(rt, orc, gpu_ctx):
     """cube.obj has only axis-aligned faces: their boxes are flat.  The reference's BVH can never hit a flat box
     (src/mesh.rs:117); here every mesh returns the brute-force result, so all faces the camera sees are hit."""

@@ -28,6 +28,14 @@ def assert_radiance_close(gpu, cpu, rel=REL):
     assert err.size == 0 or err.max() <= rel, f"max rel err {err.max():.3g}"
 
 
+def _pixel_scaled_error(ga, ca):
+    """|gpu - cpu| relative to the pixel's largest channel (terms of both signs can cancel inside one channel)."""
+    assert np.array_equal(np.isfinite(ga), np.isfinite(ca))
+    fin = np.isfinite(ca).all(axis=2)
+    scale = np.maximum(np.abs(ca[fin]).max(axis=1, keepdims=True), FLOOR)
+    return float((np.abs(ga[fin] - ca[fin]) / scale).max()) if fin.any() else 0.0
+
+
 GOLDEN = ["head_mis", "utah_mis", "cornell_mis", "mis_test_jittered", "light_test_uniform", "whitted_whitted", "whitted_path",
           "whitted_normal", "blue_noise_test_whitted"]
 
@@ -358,7 +366,7 @@ def test_occluders_next_to_the_ends_of_shadow_segments(rt, orc, gpu_ctx, shader_
     assert lit["lit"] > 0 and lit["dark"] < 0.05 * lit["lit"]
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", range(1, 17))
 def test_random_soups_of_few_triangles(rt, orc, gpu_ctx, seed):
     """Random triangles (few enough to be scanned, not walked), among them slivers, nearly coplanar pairs and faces
     a hair away from the lights: occlusion queries skip a triangle only when a whole wave is clearly off its plane,
@@ -405,11 +413,81 @@ def test_random_soups_of_few_triangles(rt, orc, gpu_ctx, seed):
         # Whitted's unclamped cosine (light.rs:79) gives terms of both signs and a light a hair from a face terms of 1e6:
         # a channel can be the small difference of large terms, and only the ORDER of the additions differs between
         # the two sides.  So the bar is relative to the pixel's largest channel, not to each channel's own value.
-        assert np.array_equal(np.isfinite(ga), np.isfinite(ca))
-        fin = np.isfinite(ca).all(axis=2)
-        scale = np.maximum(np.abs(ca[fin]).max(axis=1, keepdims=True), FLOOR)
-        err = np.abs(ga[fin] - ca[fin]) / scale
-        assert err.max() <= REL, f"max rel err {err.max():.3g}"
+        err = _pixel_scaled_error(ga, ca)
+        assert err <= REL, f"max rel err {err:.3g}"
+    ds.close()
+
+
+@pytest.mark.parametrize("seed", range(1, 33))
+def test_random_scenes_mixing_every_primitive_material_and_light(rt, orc, gpu_ctx, seed):
+    """Random rooms: spheres and cylinders of all four materials, a big mesh in a random pose (its rays walk the BVH) or
+    none, loose triangles, and one to three lights drawn from polygon / disk / point, MIS shader
+    (src/shader.rs:93-115 with src/material.rs:400-484, src/light.rs:54-411)."""
+    rng = np.random.default_rng(1000 + seed)
+    mats = [rt.diffuse(*rng.uniform(0.2, 0.9, 3)), rt.metal(*rng.uniform(0.5, 0.95, 3)), rt.dielectric(float(rng.uniform(1.2, 1.8))),
+            rt.microfacet(rng.uniform(0.02, 0.98, 3), float(rng.uniform(0.15, 0.9)), float(rng.uniform(0, 1)), rng.uniform(0.4, 1.0, 3)),
+            rt.diffuse(0.8, 0.8, 0.8)]
+    tri_v = [[-2, -1, 0, 2, -1, 0, 2, -1, -5], [-2, -1, 0, 2, -1, -5, -2, -1, -5],      # floor
+             [-2, -1, -5, 2, -1, -5, 2, 2, -5], [-2, -1, -5, 2, 2, -5, -2, 2, -5]]      # back wall
+    tri_mat = [4, 4, 0, 0]
+    objects = [rt.Object(rt.OBJ_TRIANGLE, i, 1, 0) for i in range(4)]
+    for _ in range(int(rng.integers(0, 4))):  # loose triangles of random material
+        c = rng.uniform(-1.2, 1.2, 3) + np.array([0, 0.2, -2.8])
+        tri_v.append(list(np.concatenate([c, c + rng.normal(0, 0.5, 3), c + rng.normal(0, 0.5, 3)])))
+        tri_mat.append(int(rng.integers(0, 4)))
+        objects.append(rt.Object(rt.OBJ_TRIANGLE, len(tri_v) - 1, 1, 0))
+    if rng.random() < 0.75:  # a big mesh: the teapot, any pose, any material
+        mesh = rt.load_obj(os.path.join(rt.ASSET_DIR, "utah.obj")).reshape(-1, 3)
+        mesh = rt.transform_points(mesh, float(rng.uniform(0.08, 0.2)), (float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.9, 0.0)), float(rng.uniform(-3.2, -2.0))),
+                                   float(rng.uniform(-40, 40)), float(rng.uniform(-180, 180)), float(rng.uniform(-20, 20))).reshape(-1, 9)
+        first = len(tri_v)
+        tri_v += [list(t) for t in mesh]
+        tri_mat += [int(rng.integers(0, 4))] * len(mesh)
+        objects.append(rt.Object(rt.OBJ_MESH, first, len(mesh), 2))
+    n_sph, n_cyl = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+    sph = [[float(rng.uniform(-1.3, 1.3)), float(rng.uniform(-0.7, 0.8)), float(rng.uniform(-3.8, -1.6)), float(rng.uniform(0.15, 0.45))] for _ in range(n_sph)]
+    sph_mat = [int(rng.integers(0, 4)) for _ in range(n_sph)]
+    cyl = []
+    for _ in range(n_cyl):
+        y0 = float(rng.uniform(-1.0, 0.0))
+        cyl.append([float(rng.uniform(-1.3, 1.3)), float(rng.uniform(-3.8, -1.6)), y0, y0 + float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.1, 0.35))])
+    cyl_mat = [int(rng.integers(0, 4)) for _ in range(n_cyl)]
+    # the world's list order decides ties and primitive ids: a random merge of the three kinds (each kind's own order
+    # must follow its array)
+    queues = [objects, [rt.Object(rt.OBJ_SPHERE, i, 1, 0) for i in range(n_sph)], [rt.Object(rt.OBJ_CYLINDER, i, 1, 0) for i in range(n_cyl)]]
+    objects = []
+    while any(queues):
+        q = queues[int(rng.integers(0, 3))]
+        if q:
+            objects.append(q.pop(0))
+    lights, light_tri_v = [], []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 3))
+        spectrum = tuple(float(v) for v in rng.uniform(2, 12, 3))
+        if kind == 0:  # horizontal quad, facing down
+            cx, cz, y, hw = float(rng.uniform(-1, 1)), float(rng.uniform(-3.5, -1.5)), float(rng.uniform(1.2, 1.9)), float(rng.uniform(0.1, 0.4))
+            a, b, c_, d_ = (cx - hw, y, cz - hw), (cx + hw, y, cz - hw), (cx + hw, y, cz + hw), (cx - hw, y, cz + hw)
+            lights.append(rt.Light(rt.LIGHT_POLYGON, (0, 0, 0), 0, spectrum, len(light_tri_v), 2, 1))
+            light_tri_v += [list(a + b + c_), list(a + c_ + d_)]
+        elif kind == 1:
+            lights.append(rt.Light(rt.LIGHT_DISK, (float(rng.uniform(-1, 1)), float(rng.uniform(1.0, 1.8)), float(rng.uniform(-3.5, -1.5))), float(rng.uniform(0.15, 0.5)),
+                                   spectrum, 0, 0, int(rng.integers(1, 5))))
+        else:
+            lights.append(rt.Light(rt.LIGHT_POINT, (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0.5, 1.8)), float(rng.uniform(-3.5, -0.5))), 0, spectrum, 0, 0, 1))
+    sc = rt.NumpyScene(tri_v=np.array(tri_v, np.float32), tri_mat=tri_mat, sph=sph or None, sph_mat=sph_mat or None, cyl=cyl or None, cyl_mat=cyl_mat or None,
+                       mats=mats, lights=lights, light_tri_v=light_tri_v or None, objects=objects)
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc, bvh_on_device=(seed % 4 == 0))  # every fourth scene: the tree built on the GPU
+    osc = orc.OracleScene(sc.desc, 1, sc)
+    cam = rt.camera_new((float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.2, 0.8)), 2), (0, -0.2, -2.5), (0, 1, 0), 90.0, 4 / 3)
+    p = rt.default_params(64, 48, 3, seed=seed, max_depth=int(rng.integers(3, 41)), flags=int(rng.choice([0, 0, 0, 4, 8, 12])))  # some with the options beyond the reference
+    gp, gt = ds.primary_hits(cam, p)
+    cp, ct = osc.primary_hits(cam, p)
+    assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+    ga, gs = ds.render(cam, p)
+    ca, cs = osc.render(cam, p)
+    assert gs.camera_samples == cs.camera_samples
+    err = _pixel_scaled_error(ga, ca)
+    assert err <= REL, f"max rel err {err:.3g}"
     ds.close()
 
 

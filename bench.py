@@ -210,6 +210,11 @@ def main() -> int:
         queued = shadow - inline
         shadow_per_node = queued / max(1, closest)
         inline_per_node = inline / max(1, closest)
+        # nodes that carried their path's light: 16 B more read, 16 B more written for the successor; what such paths gather
+        # (the in-place queries' contributions among it) reaches the pixel as ONE add per path instead of one per query
+        carrying = sum(s.nodes_carrying for s in stats)
+        carry_per_node = carrying / max(1, closest)
+        adds_per_node = (cams / max(1, closest)) if carrying else inline_per_node
         stage_ms = {k: sum(getattr(s, "ms_" + k) for s in stats) / steps for k in ("extend", "shade", "shadow", "raygen")}
         # mean BVH work per ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
         nodes_per_ray = tris_per_ray = 0.0
@@ -226,7 +231,7 @@ def main() -> int:
         cache_bytes_per_ray = 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
         per_unit = {  # kernel: (units over the timed steps, algorithmic HBM bytes per unit, launches, total ms)
             "k_extend": (closest, 32 + 8, sum(s.launches_extend for s in stats), sum(s.ms_extend for s in stats)),
-            "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node + 12 * inline_per_node, sum(s.launches_shade for s in stats),
+            "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node + 12 * adds_per_node + 32 * carry_per_node, sum(s.launches_shade for s in stats),
                         sum(s.ms_shade for s in stats)),
             "k_shadow": (queued, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
         }

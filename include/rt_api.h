@@ -152,6 +152,8 @@ typedef struct rt_stats {
     double ms_extend, ms_shade, ms_shadow, ms_raygen; /* RT_FLAG_TIMING: summed HIP-event durations */
     uint64_t device_bytes;   /* device memory the context holds for queues and planes after this call */
     uint64_t rays_shadow_inline; /* of rays_shadow: answered by the shading kernel itself, never written to the shadow queue */
+    uint64_t nodes_carrying;     /* of rays_closest: path nodes that brought the light gathered so far along (16 more bytes read,
+                                    and written for their successor), to be added to the pixel once at the path's end */
 } rt_stats;
 
 typedef struct rt_context rt_context;

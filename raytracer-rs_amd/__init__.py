@@ -82,7 +82,7 @@ class Stats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("iterations", C.c_uint64),
                 ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("launches_shadow", C.c_uint64),
                 ("launches_raygen", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
-                ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_raygen", C.c_double), ("device_bytes", C.c_uint64), ("rays_shadow_inline", C.c_uint64)]
+                ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_raygen", C.c_double), ("device_bytes", C.c_uint64), ("rays_shadow_inline", C.c_uint64), ("nodes_carrying", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

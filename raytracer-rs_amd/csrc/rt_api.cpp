@@ -79,7 +79,7 @@ struct rt_context {
     hipEvent_t shadow_done = nullptr;
     // queue pool, sized on demand
     uint32_t capacity = 0, shadow_capacity = 0;
-    DevBuf<float4> qa[2], qb[2], qc[2], sa[2], sb[2];
+    DevBuf<float4> qa[2], qb[2], qc[2], ql[2], sa[2], sb[2];
     DevBuf<float2> hit, sc2[2];
     DevBuf<float> planes, accum_tmp;
     DevBuf<int32_t> blocks, prim_tmp;
@@ -110,7 +110,7 @@ struct rt_scene {
 // colour planes, the list of selected 8x8 blocks and the loop state.  rt_render points it at the context's pool (grown
 // on demand with hipMalloc); rt_render_static points it at a fixed array that exists from library load on.
 struct RenderPool {
-    float4 *qa[2], *qb[2], *qc[2], *sa[2], *sb[2];
+    float4 *qa[2], *qb[2], *qc[2], *ql[2], *sa[2], *sb[2];
     float2 *hit, *sc2[2];
     float *planes;
     int32_t *blocks;
@@ -129,7 +129,7 @@ struct RenderPool {
 #define RT_STATIC_OFF_BLOCKS (RT_STATIC_OFF_CTL + RT_STATIC_ALIGN(sizeof(Ctl)))
 #define RT_STATIC_OFF_PLANES (RT_STATIC_OFF_BLOCKS + RT_STATIC_ALIGN((RT_STATIC_MAX_PIXELS / 64) * sizeof(int32_t)))
 #define RT_STATIC_OFF_NODES (RT_STATIC_OFF_PLANES + RT_STATIC_ALIGN(3 * RT_STATIC_MAX_PIXELS * sizeof(float)))
-#define RT_STATIC_OFF_HIT (RT_STATIC_OFF_NODES + 6 * RT_STATIC_CAPACITY * sizeof(float4))
+#define RT_STATIC_OFF_HIT (RT_STATIC_OFF_NODES + 8 * RT_STATIC_CAPACITY * sizeof(float4))
 #define RT_STATIC_OFF_SHADOW (RT_STATIC_OFF_HIT + RT_STATIC_CAPACITY * sizeof(float2))
 #define RT_STATIC_SCRATCH_BYTES (RT_STATIC_OFF_SHADOW + RT_STATIC_CAPACITY * (4 * sizeof(float4) + 2 * sizeof(float2)))
 
@@ -224,6 +224,7 @@ int ensure_queues(rt_context *ctx, uint32_t capacity, uint32_t shadow_capacity, 
             HIP_TRY_ALLOC(ctx->qa[k].ensure(capacity));
             HIP_TRY_ALLOC(ctx->qb[k].ensure(capacity));
             HIP_TRY_ALLOC(ctx->qc[k].ensure(capacity));
+            HIP_TRY_ALLOC(ctx->ql[k].ensure(capacity));
         }
         HIP_TRY_ALLOC(ctx->hit.ensure(capacity));
         ctx->capacity = capacity;
@@ -370,7 +371,7 @@ int32_t rt_context_destroy(rt_context *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int k = 0; k < 2; k++) { ctx->qa[k].release(); ctx->qb[k].release(); ctx->qc[k].release(); }
+    for (int k = 0; k < 2; k++) { ctx->qa[k].release(); ctx->qb[k].release(); ctx->qc[k].release(); ctx->ql[k].release(); }
     ctx->hit.release();
     for (int k = 0; k < 2; k++) { ctx->sa[k].release(); ctx->sb[k].release(); ctx->sc2[k].release(); }
     ctx->planes.release(); ctx->accum_tmp.release(); ctx->blocks.release(); ctx->prim_tmp.release(); ctx->t_tmp.release();
@@ -766,6 +767,15 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         uint32_t chunk_samples = env_u32("RT_TILE_SAMPLES", 16);
         while (chunk_samples > 1 && (unsigned long long)n_blocks * 64ull * chunk_samples >= (1ull << 30)) chunk_samples /= 2;
         ctx->ctl_host->chunk_samples = chunk_samples;
+        // Path nodes carry the light gathered so far and add it to the pixel once, at the path's end (RT_CARRY=0: every
+        // contribution is added where it arises).  Not for the Whitted shader: all its light arrives through queued shadow rays.
+        // It pays where most occlusion queries are answered by the shading kernel (their contributions then never
+        // become atomic adds) and costs 16 bytes of traffic per node where they are not, so it follows the same rule as
+        // the in-place queries, decided once: the first iteration's children carry, the second iteration sees how the
+        // rays split into light and heavy and either goes on or adds what the nodes brought and stops carrying.
+        const uint32_t carry_mode = p->shader == RT_SHADER_WHITTED || s->dev.n_loose < 0 ? 0u : env_u32_allow_zero("RT_CARRY", 1); // 0 never, 1 by the rule, 2 always
+        bool carry_in = false, carry_out = carry_mode != 0;
+        int carry_decided = carry_mode == 1 ? 0 : 1;
         HIP_TRY(hipMemcpyAsync(&pool.ctl->h, ctx->ctl_host, sizeof(CtlHead), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         int cur = 0, scur = 0;
@@ -805,8 +815,8 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
                 st.launches_shadow++;
             }
             if (c.done) break;
-            NodeQueue in{pool.qa[cur], pool.qb[cur], pool.qc[cur]};
-            NodeQueue out{pool.qa[cur ^ 1], pool.qb[cur ^ 1], pool.qc[cur ^ 1]};
+            NodeQueue in{pool.qa[cur], pool.qb[cur], pool.qc[cur], pool.ql[cur]};
+            NodeQueue out{pool.qa[cur ^ 1], pool.qb[cur ^ 1], pool.qc[cur ^ 1], pool.ql[cur ^ 1]};
             ShadowQueue sh{pool.sa[scur], pool.sb[scur], pool.sc2[scur]};
             if (c.n_new) {
                 timer.begin(3);
@@ -823,7 +833,12 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             if (tail_limit && c.n_new == 0 && c.cursor == c.total && c.n_alive <= tail_limit) {
                 // the last few paths: one launch follows each of them to its end (see k_tail)
                 timer.begin(0);
-                launch_tail(cfg, p->shader, s->dev, rcst, pool.ctl, in, out, pool.planes, (uint32_t)plane_stride, light_threads, heavy_threads);
+                DevScene dev_tail = s->dev;
+                if (carry_in) st.nodes_carrying += c.n_alive;
+                dev_tail.carry_in = carry_in ? 1 : 0;
+                dev_tail.carry_out = carry_in ? 1 : 0; // (a second child that overflows the thread's stack goes to the next queue)
+                carry_out = carry_in;
+                launch_tail(cfg, p->shader, dev_tail, rcst, pool.ctl, in, out, pool.planes, (uint32_t)plane_stride, light_threads, heavy_threads);
                 timer.end();
                 st.launches_extend++;
                 hipError_t le = hipGetLastError();
@@ -840,11 +855,20 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             // (Utah teapot: 5 %), +1 to +2.5 % when none are (the occlusion kernel then overlaps with everything on the
             // second stream) or when many are (Miku, composite).  The choice only moves work: results are the same.
             DevScene dev_now = s->dev;
+            const bool few_heavy = c.max_in_heavy > 0 && 4u * c.max_in_heavy < c.max_in_light;
+            if (!carry_decided && c.n_alive > 0) { // the first iteration that carries nodes in: they are the first children
+                carry_out = s->dev.inline_shadow >= 2 || (s->dev.inline_shadow == 1 && few_heavy);
+                carry_decided = 1;
+            }
+            dev_now.carry_in = carry_in ? 1 : 0;
+            dev_now.carry_out = carry_out ? 1 : 0;
+            if (carry_in) st.nodes_carrying += c.n_alive;
             dev_now.inline_shadow = s->dev.inline_shadow >= 2 || (s->dev.inline_shadow == 1 && c.max_in_heavy > 0 && 4u * c.max_in_heavy < c.max_in_light) ? 1 : 0;
             timer.begin(1);
             launch_shade(cfg, p->shader, dev_now, rcst, pool.ctl, in, out, pool.hit, sh, pool.planes, (uint32_t)plane_stride, light_threads, heavy_threads);
             timer.end();
             st.launches_shade++;
+            carry_in = carry_out; // the queue just written is the one read next
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
             cur ^= 1;
@@ -931,13 +955,13 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         // and the uneven split between light and heavy segments must fit; running out of room is reported, never silent
         seg_capacity = 8u * (target / RT_NSEG);
         shadow_seg_capacity = (per_node > 1 ? 4u * (target / RT_NSEG) * per_node : seg_capacity);
-        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 48 + 8) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
+        const size_t need = (size_t)seg_capacity * RT_NSEG * (2 * 64 + 8) + (size_t)shadow_seg_capacity * RT_NSEG * (2 * 40);
         const bool grows = (size_t)seg_capacity * RT_NSEG > ctx->capacity || (size_t)shadow_seg_capacity * RT_NSEG > ctx->shadow_capacity;
         if (target_given || !grows || target <= (1u << 20)) break;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
         if (const uint32_t pretend_mb = env_u32("RT_FREE_MEM_MB", 0)) free_b = (size_t)pretend_mb << 20; // for tests of this fallback
-        const size_t held = ctx->capacity * (size_t)(2 * 48 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
+        const size_t held = ctx->capacity * (size_t)(2 * 64 + 8) + ctx->shadow_capacity * (size_t)(2 * 40); // freed and re-allocated on growth
         if (need <= (free_b + held) / 2) break;
         target /= 2;
     }
@@ -952,7 +976,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     RenderPool pool;
     for (int k = 0; k < 2; k++) {
-        pool.qa[k] = ctx->qa[k].p; pool.qb[k] = ctx->qb[k].p; pool.qc[k] = ctx->qc[k].p;
+        pool.qa[k] = ctx->qa[k].p; pool.qb[k] = ctx->qb[k].p; pool.qc[k] = ctx->qc[k].p; pool.ql[k] = ctx->ql[k].p;
         pool.sa[k] = ctx->sa[k].p; pool.sb[k] = ctx->sb[k].p; pool.sc2[k] = ctx->sc2[k].p;
     }
     pool.hit = ctx->hit.p; pool.planes = ctx->planes.p; pool.blocks = ctx->blocks.p; pool.ctl = ctx->ctl;
@@ -964,7 +988,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    st.device_bytes = (uint64_t)ctx->capacity * (2 * 48 + 8) + (uint64_t)ctx->shadow_capacity * (2 * 40) + (uint64_t)ctx->planes.n * sizeof(float) +
+    st.device_bytes = (uint64_t)ctx->capacity * (2 * 64 + 8) + (uint64_t)ctx->shadow_capacity * (2 * 40) + (uint64_t)ctx->planes.n * sizeof(float) +
                       (uint64_t)ctx->accum_tmp.n * sizeof(float) + (uint64_t)ctx->blocks.n * sizeof(int32_t) + sizeof(Ctl);
     if (stats) *stats = st;
     return RT_OK;
@@ -1001,9 +1025,10 @@ int32_t rt_render_static(rt_scene *s, const rt_camera *cam, const rt_params *p, 
     pool.planes = reinterpret_cast<float *>(base + RT_STATIC_OFF_PLANES);
     float4 *nodes = reinterpret_cast<float4 *>(base + RT_STATIC_OFF_NODES);
     for (int k = 0; k < 2; k++) {
-        pool.qa[k] = nodes + (size_t)(3 * k + 0) * RT_STATIC_CAPACITY;
-        pool.qb[k] = nodes + (size_t)(3 * k + 1) * RT_STATIC_CAPACITY;
-        pool.qc[k] = nodes + (size_t)(3 * k + 2) * RT_STATIC_CAPACITY;
+        pool.qa[k] = nodes + (size_t)(4 * k + 0) * RT_STATIC_CAPACITY;
+        pool.qb[k] = nodes + (size_t)(4 * k + 1) * RT_STATIC_CAPACITY;
+        pool.qc[k] = nodes + (size_t)(4 * k + 2) * RT_STATIC_CAPACITY;
+        pool.ql[k] = nodes + (size_t)(4 * k + 3) * RT_STATIC_CAPACITY;
     }
     pool.hit = reinterpret_cast<float2 *>(base + RT_STATIC_OFF_HIT);
     float4 *sh4 = reinterpret_cast<float4 *>(base + RT_STATIC_OFF_SHADOW);

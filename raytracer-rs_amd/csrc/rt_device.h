@@ -154,6 +154,7 @@ struct DevScene {
     int32_t deferred;
     int32_t walk_span; // ... and a wave may own up to 64 * walk_span consecutive rays of a heavy segment
     int32_t walk_refill; // lanes that must be out of work before the wave retires their rays and hands out new ones
+    int32_t carry_in, carry_out; // the nodes read / the nodes written carry the light their path has gathered (NodeQueue::l)
     const int32_t *tri_of_prim; // primitive id -> index into tris (-1 for spheres and cylinders)
     float heavy_min[4][3];
     float heavy_max[4][3];

@@ -8,13 +8,16 @@
 
 namespace rtd {
 
-// Path-node queue (SoA, 48 B per node):
+// Path-node queue (SoA, 48 B per node, 64 B when the node carries its path's light):
 //   a = (o.x, o.y, o.z, d.x)   b = (d.y, d.z, w.x, w.y)   c = (w.z, b_pdf, meta, node_key)
 // w = path weight so far times the BSDF value of the last bounce; the divisor (light pdf + b_pdf) of that bounce is
 // applied when the node is shaded, once the extend stage knows which light the ray meets (LightList::pdf).
 // meta = pixel (24 bits) | depth << 24 | root << 30.
+// l = (L.x, L.y, L.z, -): light already gathered along the path (emission met, next-event samples whose occlusion
+// query the shading kernel answered itself), carried to the path's end and added to the pixel once — when
+// DevScene::carry_out / carry_in say so; otherwise l is neither written nor read and every contribution is added where it arises.
 struct NodeQueue {
-    float4 *a, *b, *c;
+    float4 *a, *b, *c, *l;
 };
 
 // Shadow-ray queue (40 B per ray): a = (o.xyz, d.x), b = (d.yz, c.x, c.y), c = (c.z, pixel); c = contribution added

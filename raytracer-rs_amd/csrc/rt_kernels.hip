@@ -159,10 +159,18 @@ struct Node {
     uint32_t meta, nk;
 };
 __device__ __forceinline__ uint32_t make_meta(uint32_t pixel, uint32_t depth, uint32_t root) { return pixel | (depth << 24) | (root << 30); }
-__device__ __forceinline__ void store_node(const NodeQueue &q, uint32_t i, const Node &n) {
+__device__ __forceinline__ F3 load_light(const NodeQueue &q, uint32_t i, uint32_t meta) { // what node i's path has gathered; nothing for a camera ray
+    if ((meta >> 30) & 1u) return f3(0.0f, 0.0f, 0.0f);
+    const float4 l = q.l[i];
+    return f3(l.x, l.y, l.z);
+}
+// `carry`: the node's gathered light travels with it.  Camera rays (root nodes) carry nothing: k_raygen does not write
+// l, and a reader ignores what it finds there.
+__device__ __forceinline__ void store_node(const NodeQueue &q, uint32_t i, const Node &n, bool carry = false, F3 light = F3{0.0f, 0.0f, 0.0f}) {
     q.a[i] = make_float4(n.o.x, n.o.y, n.o.z, n.d.x);
     q.b[i] = make_float4(n.d.y, n.d.z, n.w.x, n.w.y);
     q.c[i] = make_float4(n.w.z, n.b_pdf, __uint_as_float(n.meta), __uint_as_float(n.nk));
+    if (carry) q.l[i] = make_float4(light.x, light.y, light.z, 0.0f);
 }
 __device__ __forceinline__ Node load_node(const NodeQueue &q, uint32_t i) {
     float4 a = q.a[i], b = q.b[i], c = q.c[i];
@@ -466,10 +474,12 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
 // What shading one node yields: up to two children, one next-event shadow ray (or, for the Whitted shader, the surface
 // point whose light samples the caller expands).  Emission and the 0 * inf of a miss are added to the pixel here.
 struct ShadeResult {
+    // light this node adds to its path: emission met by its ray, or the 0 * inf / 0 * NaN of a miss with a non-finite
+    // weight; the value sits in c0.w (such a node has no children), `ended` says so.
+    bool ended = false;
     bool have0 = false, have1 = false, have_s = false;
     Node c0, c1;
     F3 s_o = {0.0f, 0.0f, 0.0f}, s_d = {0.0f, 0.0f, 1.0f}, s_c = {0.0f, 0.0f, 0.0f};
-    uint32_t s_pixel = 0;
     // Whitted's LightList::visible needs several shadow rays per surface point; they are produced after the main body
     bool vis_pending = false;
     F3 vis_p, vis_n, vis_w;
@@ -524,9 +534,10 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
     const bool light_wins = li >= 0 && (!obj || !(t_l > t_obj)); // shader.rs:101,108-112
     if (light_wins) {
         const DevLight &L = sc.lights[li];
-        add_pixel(planes, n_pixels, tiled_index(rc, pixel), mul_v(beta, f3(L.sx, L.sy, L.sz)));
+        r.ended = true;
+        r.c0.w = mul_v(beta, f3(L.sx, L.sy, L.sz));
     } else if (!obj) {
-        if (!all_finite(beta)) add_pixel(planes, n_pixels, tiled_index(rc, pixel), beta * 0.0f); // 0 * inf, 0 * NaN of the recursive form
+        if (!all_finite(beta)) { r.ended = true; r.c0.w = beta * 0.0f; } // 0 * inf, 0 * NaN of the recursive form
     } else {
         const F3 p = nd.o + t_obj * nd.d; // ray.rs:9-11
         F3 n;
@@ -551,7 +562,7 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 F3 c = mul_v(beta, direct);
                 if (!is_black(c)) {
                     r.have_s = true;
-                    r.s_o = p; r.s_d = ldir; r.s_c = c; r.s_pixel = tiled_index(rc, pixel);
+                    r.s_o = p; r.s_d = ldir; r.s_c = c;
                 }
             }
             F3 sd;
@@ -572,8 +583,6 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have0 = true;
                     r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = pdf;
-                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
-                    r.c0.nk = child_node_key(nd.nk, 0u);
                 }
             }
             if (m.kind == RT_MAT_MICROFACET) { // the diffuse lobe of material.rs:416-438
@@ -589,9 +598,7 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 if (rr && !roulette(m, pk, nd.nk, P_ROULETTE1, d1, &w)) w = f3(0.0f, 0.0f, 0.0f);
                 if (d1 <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have1 = true;
-                    r.c1.o = p; r.c1.d = dd; r.c1.w = w; r.c1.b_pdf = 1.0f / RTD_PI;
-                    r.c1.meta = make_meta(pixel, d1, 0u);
-                    r.c1.nk = child_node_key(nd.nk, 1u);
+                    r.c1.o = p; r.c1.d = dd; r.c1.w = w;
                 }
             }
         } else if (SHADER == RT_SHADER_PATH) { // shader.rs:68-80
@@ -605,8 +612,6 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have0 = true;
                     r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = 1.0f;
-                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
-                    r.c0.nk = child_node_key(nd.nk, 0u);
                 }
             }
         } else { // RT_SHADER_WHITTED, shader.rs:32-45
@@ -617,16 +622,25 @@ __device__ __forceinline__ void shade_node(const SC &sc, const RenderConst &rc, 
                 if (depth + 1u <= (uint32_t)rc.max_depth && !is_black(w)) {
                     r.have0 = true;
                     r.c0.o = p; r.c0.d = sd; r.c0.w = w; r.c0.b_pdf = 1.0f;
-                    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
-                    r.c0.nk = child_node_key(nd.nk, 0u);
                 }
             } else if (!is_black(w)) {
                 r.vis_pending = true;
                 r.vis_p = p; r.vis_n = n; r.vis_w = w; r.vis_pk = pk; r.vis_nk = nd.nk;
-                r.s_pixel = tiled_index(rc, pixel);
             }
         }
     }
+}
+
+// What shade_node leaves out of the children it makes, because it follows from the parent alone and would only occupy
+// registers until the children are stored: depth and pixel (meta), the node keys, the constant density of the diffuse
+// lobe (material.rs:433-437).  Called where the children are about to be used.
+__device__ __forceinline__ void finish_children(const RenderConst &rc, const Node &nd, ShadeResult &r) {
+    const uint32_t pixel = nd.meta & 0xFFFFFFu, depth = (nd.meta >> 24) & 63u;
+    r.c0.meta = make_meta(pixel, depth + 1u, 0u);
+    r.c0.nk = child_node_key(nd.nk, 0u);
+    r.c1.meta = make_meta(pixel, max(depth, (uint32_t)max(rc.max_depth - 6, 0)) + 1u, 0u);
+    r.c1.nk = child_node_key(nd.nk, 1u);
+    r.c1.b_pdf = 1.0f / RTD_PI;
 }
 
 // One shadow ray per lane for the Whitted shader's LightList::visible (light.rs:368-385), appended to the light or the
@@ -740,6 +754,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADER ==
     const uint32_t il = bx * BLOCK + threadIdx.x;
     // node and hit record are fetched before the fill count is known, like the ray of k_extend
     const uint32_t i = seg * seg_capacity + min(il, seg_capacity - 1u);
+    // carry_in: the nodes read bring the light their paths have gathered; carry_out: the children take it along (else it
+    // is added to the pixel here).  They differ only in the one iteration in which the host gives carrying up.
+    const bool carry_in = SHADER != RT_SHADER_WHITTED && sc.carry_in != 0, carry = SHADER != RT_SHADER_WHITTED && sc.carry_out != 0;
     const Node nd_early = load_node(in, i);
     const float2 h_early = hit[i];
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
@@ -752,9 +769,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADER ==
     bool answered = false; // a light occlusion query answered in place, see below
     bool s_heavy = false;  // the occlusion query's ray touches the box of a big mesh
     bool heavy0 = false, heavy1 = false;
+    bool lit = false; // the occlusion query answered in place found the light visible
+    F3 carried = f3(0.0f, 0.0f, 0.0f);
     uint32_t slot[3];
     auto shade = [&](const auto &view) {
         if (il < n_seg) shade_node<SHADER, EXT>(view, rc, planes, n_pixels, nd_early, h_early, r);
+        if (carry_in && il < n_seg) carried = load_light(in, i, nd_early.meta); // fetched here, not with the node: three registers less while shading
         // ---- compaction: children into the next queue, shadow rays into the shadow queue, light and heavy rays apart
         s_heavy = SHADER != RT_SHADER_WHITTED && r.have_s && ray_is_heavy(sc, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min);
         heavy0 = r.have0 && ray_is_heavy(sc, r.c0.o, r.c0.d, rc.t_min, rc.t_max);
@@ -771,7 +791,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADER ==
             if (in_place && __ballot(answered) != 0ull) {
                 uint32_t nn = 0, nt = 0;
                 const bool occ = answered && world_occluded<false, false, true>(view, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
-                if (answered && !occ) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
+                lit = answered && !occ;
+                if (lit && !carry) add_pixel(planes, n_pixels, tiled_index(rc, nd_early.meta & 0xFFFFFFu), r.s_c);
             }
         });
     };
@@ -783,16 +804,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SHADER ==
     const bool have0 = r.have0, have1 = r.have1, have_s = r.have_s, vis_pending = r.vis_pending;
     const Node &c0 = r.c0, &c1 = r.c1;
     const F3 s_o = r.s_o, s_d = r.s_d, s_c = r.s_c, vis_p = r.vis_p, vis_n = r.vis_n, vis_w = r.vis_w;
-    const uint32_t s_pixel = r.s_pixel, vis_pk = r.vis_pk, vis_nk = r.vis_nk;
+    finish_children(rc, nd_early, r);
+    const uint32_t s_pixel = tiled_index(rc, nd_early.meta & 0xFFFFFFu), vis_pk = r.vis_pk, vis_nk = r.vis_nk;
     const bool nee = SHADER != RT_SHADER_WHITTED && have_s;
     const bool heavy_s = nee && s_heavy;
     const bool queued = nee && !answered;
     const uint32_t seg3[3] = {ray_segment(heavy0, oseg_l), ray_segment(heavy1, oseg_l), ray_segment(heavy_s, oseg_l)};
+    // Light of this node: what its ray met plus, carried, what the path brought along and the next-event sample found
+    // visible in place.  It travels on with the first child there is; a path that ends here adds it to its pixel.
+    F3 light = f3(0.0f, 0.0f, 0.0f);
+    if (il < n_seg) {
+        if (r.ended) light = c0.w;
+        if (carry_in) light = carried + light;
+        if (carry && lit) light = light + s_c;
+        if (!(carry && (have0 || have1)) && !is_black(light)) add_pixel(planes, n_pixels, tiled_index(rc, nd_early.meta & 0xFFFFFFu), light);
+    }
+    const F3 none = f3(0.0f, 0.0f, 0.0f);
     if (have0) {
-        if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0); else ctl->h.overflow = 1;
+        if (slot[0] < seg_capacity) store_node(out, seg3[0] * seg_capacity + slot[0], c0, carry, light); else ctl->h.overflow = 1;
     }
     if (have1) {
-        if (slot[1] < seg_capacity) store_node(out, seg3[1] * seg_capacity + slot[1], c1); else ctl->h.overflow = 1;
+        if (slot[1] < seg_capacity) store_node(out, seg3[1] * seg_capacity + slot[1], c1, carry, have0 ? none : light); else ctl->h.overflow = 1;
     }
     if (SHADER == RT_SHADER_WHITTED) {
         // LightList::visible (light.rs:368-385): every light; a disk light is sampled light_samples times (light.rs:150-181)
@@ -956,7 +988,11 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl
     const uint32_t n_seg = min(ctl->seg_in[seg].v, seg_capacity);
     const uint32_t il = bx * BLOCK + threadIdx.x;
     if (il >= n_seg) return;
+    const bool carry = sc.carry_out != 0;
+    // every node this thread shades belongs to one pixel: what they gather is summed here and added once at the end
     Node nd = load_node(in, seg * seg_capacity + il);
+    F3 light = sc.carry_in ? load_light(in, seg * seg_capacity + il, nd.meta) : f3(0.0f, 0.0f, 0.0f);
+    const uint32_t pixel_index = tiled_index(rc, nd.meta & 0xFFFFFFu);
     const uint32_t oseg_l = (bx + seg) % RT_NSEG_HALF;
     uint32_t more_closest = 0, shadows = 0;
     Node pending[6];
@@ -969,16 +1005,18 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl
         world_hit<false>(sc, nullptr, nd.o, nd.d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
         ShadeResult r;
         shade_node<SHADER, EXT>(sc, rc, planes, n_pixels, nd, make_float2(t_obj, __int_as_float(code)), r);
+        finish_children(rc, nd, r);
+        if (r.ended) light = light + r.c0.w;
         if (r.have_s) {
             shadows++;
-            if (!world_occluded<false>(sc, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)) add_pixel(planes, n_pixels, r.s_pixel, r.s_c);
+            if (!world_occluded<false>(sc, nullptr, r.s_o, r.s_d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)) light = light + r.s_c;
         }
         if (r.have1) {
             if (n_pending < 6) pending[n_pending++] = r.c1;
             else {
                 const uint32_t oseg = ray_segment(ray_is_heavy(sc, r.c1.o, r.c1.d, rc.t_min, rc.t_max), oseg_l);
                 const uint32_t slot = atomicAdd(&ctl->seg_out[oseg].v, 1u);
-                if (slot < seg_capacity) store_node(out, oseg * seg_capacity + slot, r.c1); else ctl->h.overflow = 1;
+                if (slot < seg_capacity) store_node(out, oseg * seg_capacity + slot, r.c1, carry); else ctl->h.overflow = 1; // (carries nothing: L = 0)
             }
         }
         if (r.have0) nd = r.c0;
@@ -986,6 +1024,7 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, RenderConst rc, Ctl
         else break;
         more_closest++;
     }
+    if (!is_black(light)) add_pixel(planes, n_pixels, pixel_index, light);
     // the first ray of every path is counted by k_plan with the queue, the others here
     if (more_closest) atomicAdd(&ctl->h.rays_closest, (unsigned long long)more_closest);
     if (shadows) atomicAdd(&ctl->h.rays_shadow, (unsigned long long)shadows);

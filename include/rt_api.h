@@ -206,7 +206,7 @@ int32_t rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params
  * No counterpart in the reference.  rt_render for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and results as rt_render with
  * accum_is_device != 0 (accum_rgb_dev must be a device pointer), but the path queues, hit records, shadow queues,
- * colour planes and loop counters live in a fixed array in device memory (about 122 MB per GPU, held from library
+ * colour planes and loop counters live in a fixed array in device memory (about 139 MB per GPU, held from library
  * load until the process ends) instead of the context's pool, and the call creates no events: it calls no hipMalloc,
  * hipFree or other allocating routine.  Limits, rejected with RT_ERR_INVALID: ceil(width/8)*ceil(height/8)*64 <= 2^21
  * pixels (1920x1080 fits), RT_FLAG_TIMING not set, and for the Whitted shader at most 64 shadow rays per surface

@@ -226,6 +226,32 @@ def test_roulette_keeps_the_mean_and_shortens_paths(rt, gpu_ctx, monkeypatch):
     ds.close()
 
 
+def test_light_carried_along_the_path_gives_the_same_image(rt, gpu_ctx, monkeypatch):
+    """RT_CARRY: path nodes bring along what their path has gathered and add it to the pixel once (0 never, 1 where most
+    occlusion queries are answered by the shading kernel, 2 always).  Same rays, same image; rt_stats.nodes_carrying
+    says how many nodes carried."""
+    hs = rt.HostScene("utah", 16 / 9)  # few rays touch the teapot: the rule chooses to carry
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    p = rt.default_params(160, 90, 8)
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("RT_CARRY", mode)
+        out[mode] = ds.render(hs.camera, p)
+    (a0, s0), (a1, s1), (a2, s2) = out["0"], out["1"], out["2"]
+    assert s0.nodes_carrying == 0 and s1.nodes_carrying > 0 and s2.nodes_carrying >= s1.nodes_carrying
+    assert s2.nodes_carrying <= s2.rays_closest - s2.camera_samples
+    for a, s in ((a1, s1), (a2, s2)):
+        assert (s.rays_closest, s.rays_shadow, s.camera_samples) == (s0.rays_closest, s0.rays_shadow, s0.camera_samples)
+        assert_radiance_close(a, a0, rel=1e-5)
+    ds.close()
+    hs = rt.HostScene("miku", 16 / 9)  # most rays touch the mesh: the rule gives carrying up after the first children
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    monkeypatch.setenv("RT_CARRY", "1")
+    _, s = ds.render(hs.camera, rt.default_params(96, 54, 4))
+    assert 0 < s.nodes_carrying < 96 * 54 * 4
+    ds.close()
+
+
 def test_tail_kernel_traces_the_same_rays(rt, gpu_ctx, monkeypatch):
     """The last paths of a call are followed to their end by one kernel launch instead of one wavefront iteration per
     bounce (RT_TAIL = population at which that starts, 0 = never): same rays, same image, fewer iterations."""

@@ -472,7 +472,9 @@ __device__ __forceinline__ bool nee_sample(const SC &sc, const RenderConst &rc, 
 }
 
 // What shading one node yields: up to two children, one next-event shadow ray (or, for the Whitted shader, the surface
-// point whose light samples the caller expands).  Emission and the 0 * inf of a miss are added to the pixel here.
+// point whose light samples the caller expands), and the light its ray met.  Nothing is added to the pixel here: the
+// caller adds, or lets the path carry.  Of a child only origin, direction, weight and density are filled in; see
+// finish_children for the rest.
 struct ShadeResult {
     // light this node adds to its path: emission met by its ray, or the 0 * inf / 0 * NaN of a miss with a non-finite
     // weight; the value sits in c0.w (such a node has no children), `ended` says so.

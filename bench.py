@@ -218,6 +218,7 @@ def main() -> int:
         stage_ms = {k: sum(getattr(s, "ms_" + k) for s in stats) / steps for k in ("extend", "shade", "shadow", "raygen")}
         # mean BVH work per ray, counted in a separate (untimed, slower) pass over 1 sample per pixel
         nodes_per_ray = tris_per_ray = 0.0
+        walk_per_ray = {}  # kernel -> (tree nodes visited, tree-leaf triangles tested) per ray of that kernel
         if not args.no_count_pass:
             cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK)
             cp.spp_begin, cp.spp_end = 0, 1
@@ -227,6 +228,10 @@ def main() -> int:
             n_rays_counted = max(1, cst.rays_closest + cst.rays_shadow)
             nodes_per_ray = cst.nodes_visited / n_rays_counted
             tris_per_ray = cst.tris_tested / n_rays_counted
+            c_queued = max(1, cst.rays_shadow - cst.rays_shadow_inline)
+            walk_per_ray = {"k_extend": ((cst.nodes_visited - cst.nodes_visited_shadow) / max(1, cst.rays_closest),
+                                         (cst.tris_tested - cst.tris_tested_shadow - cst.tris_scanned) / max(1, cst.rays_closest)),
+                            "k_shadow": (cst.nodes_visited_shadow / c_queued, cst.tris_tested_shadow / c_queued)}
         d = hs.desc
         cache_bytes_per_ray = 32 * nodes_per_ray + 48 * tris_per_ray + 16 * d.n_sph + 20 * d.n_cyl
         per_unit = {  # kernel: (units over the timed steps, algorithmic HBM bytes per unit, launches, total ms)
@@ -259,9 +264,45 @@ def main() -> int:
                                  "frac": round(achieved / 8000.0, 4), "traffic": measured_traffic.get(name), "avg_launch_ms": round(avg_ms, 4),
                                  "launches_per_step": launches / steps, "units_per_launch": round(units / launches, 1),
                                  "bytes_per_unit": round(bpu, 1), "ms_per_step": round(ms / steps, 2)}
+        # ---- the walk kernels' own roofline: per-lane ("divergent") 16-byte loads per second.  A visited tree node is one such
+        # load, a tested leaf triangle three (its 48-byte record); the scene (a few MB) stays in L2, so these never become
+        # HBM traffic and the HBM figure above says nothing about a walk.  Peak = what tools/ta_rate measures on this GPU for
+        # a table of the scene's footprint: the best rate of per-lane 16-byte buffer loads at random slots, 64 different
+        # cache lines per wave-instruction (independent loads, dependent chains, chains of pairs; 2 to 8 waves per SIMD).
+        info = ds.info
+        footprint = info.n_nodes * info.n_orders * 16 + info.n_triangles * 48
+        ta = None
+        ta_path = os.path.join(ROOT, "tools", "ta_rate")
+        if walk_per_ray and info.n_nodes > 0 and os.path.exists(ta_path):
+            import subprocess
+            try:
+                out = subprocess.run([ta_path, "--json", "--footprint", str(max(footprint, 1 << 16))], capture_output=True, text=True, timeout=120)
+                ta = json.loads(out.stdout)
+            except Exception as e:  # the figure is then simply missing
+                print(f"bench.py: tools/ta_rate failed: {e}", file=sys.stderr)
+        if ta:
+            rows16 = [r for r in ta["rows"] if r["bytes"] == 16 and r["what"].startswith("divergent") and r["active_lanes"] == 64]
+            peak_row = max(rows16, key=lambda r: r["Glane_per_s"])
+            for name, (n_node, n_tri) in walk_per_ray.items():
+                if name not in kernels or n_node <= 0:
+                    continue
+                k = kernels[name]
+                acc_per_ray = n_node + 3.0 * n_tri
+                achieved = acc_per_ray * k["units_per_launch"] / (k["avg_launch_ms"] * 1e-3) / 1e9
+                k["l1_access"] = {"bound": "l1_access", "kernel": name, "achieved": round(achieved, 1), "peak": round(peak_row["Glane_per_s"], 1),
+                                  "unit": "G per-lane 16-byte loads/s", "frac": round(achieved / peak_row["Glane_per_s"], 4), "traffic": None,
+                                  "accesses_per_ray": round(acc_per_ray, 2), "nodes_per_ray": round(n_node, 2), "leaf_triangles_per_ray": round(n_tri, 2),
+                                  "peak_from": f"tools/ta_rate, table of {ta['footprint_bytes']} bytes: {peak_row['what']}, {peak_row['waves_per_simd']} waves per SIMD",
+                                  "avg_launch_ms": k["avg_launch_ms"], "units_per_launch": k["units_per_launch"]}
         roofline = None
         if kernels:
             dom = max(kernels.values(), key=lambda k: k["ms_per_step"])
+            if "l1_access" in dom and dom["l1_access"]["frac"] > dom["frac"]:
+                # a walk kernel dominates: its bound is the rate of per-lane loads, not HBM
+                hbm = {kk: dom[kk] for kk in ("achieved", "peak", "unit", "frac", "bytes_per_unit")}
+                dom = dict(dom, **dom["l1_access"])
+                dom["hbm"] = hbm
+                dom.pop("l1_access", None)
             roofline = dict(dom)
             roofline["note"] = ("HBM roofline of the kernel with the largest share of the step; traversal kernels are bound by divergence and "
                                 "L1/L2 latency, not HBM: BVH/triangle fetches (cache_bytes_per_ray) never leave the caches.  k_shadow of one "
@@ -289,8 +330,17 @@ def main() -> int:
             roofline["cache_bytes_per_ray"] = round(cache_bytes_per_ray, 1)
             roofline["nodes_per_ray"] = round(nodes_per_ray, 2)
             roofline["tris_per_ray"] = round(tris_per_ray, 2)
-            roofline["all_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "avg_launch_ms", "bytes_per_unit", "ms_per_step", "traffic")}
+            roofline["all_kernels"] = {k: {kk: v[kk] for kk in ("achieved", "frac", "avg_launch_ms", "bytes_per_unit", "ms_per_step", "traffic", "l1_access") if kk in v}
                                        for k, v in kernels.items()}
+            if ta:
+                both = sum((walk_per_ray[n][0] + 3.0 * walk_per_ray[n][1]) * kernels[n]["units_per_launch"] * kernels[n]["launches_per_step"]
+                           for n in walk_per_ray if n in kernels)
+                roofline["walk_kernels_together"] = {
+                    "note": "k_extend and k_shadow run side by side on two streams, so each one's launch time includes the other's share of the GPU: "
+                            "per-lane loads of both over the whole step",
+                    "achieved": round(both / (ms_per_step * 1e-3) / 1e9, 1), "peak": round(peak_row["Glane_per_s"], 1),
+                    "frac": round(both / (ms_per_step * 1e-3) / 1e9 / peak_row["Glane_per_s"], 4), "unit": "G per-lane 16-byte loads/s"}
+                roofline["ta_rate"] = ta
 
         # ---- CPU baseline: the oracle (a restatement of the reference, not the Rust binary) on a bounded sample
         cpu = None

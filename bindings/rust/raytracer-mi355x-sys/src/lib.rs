@@ -34,9 +34,10 @@ pub const RT_ERR_NOMEM: i32 = 4;
     pub rays_shadow: u64, pub nodes_visited: u64, pub tris_tested: u64, pub iterations: u64,
     pub launches_extend: u64, pub launches_shade: u64, pub launches_shadow: u64, pub launches_raygen: u64,
     pub ms_total: f64, pub ms_extend: f64, pub ms_shade: f64, pub ms_shadow: f64, pub ms_raygen: f64,
-    pub device_bytes: u64, pub rays_shadow_inline: u64, pub nodes_carrying: u64 }
+    pub device_bytes: u64, pub rays_shadow_inline: u64, pub nodes_carrying: u64,
+    pub nodes_visited_shadow: u64, pub tris_tested_shadow: u64, pub tris_scanned: u64 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct rt_scene_info { pub n_triangles: i32, pub n_nodes: i32, pub n_orders: i32,
-    pub n_top: i32, pub bvh_on_device: i32, pub reserved: i32, pub bvh_build_ms: f64 }
+    pub n_top: i32, pub bvh_on_device: i32, pub n_loose: i32, pub bvh_build_ms: f64 }
 pub const RT_SCENE_BVH_ON_DEVICE: u32 = 1;
 pub const RT_FLAG_TIMING: u32 = 1;
 pub const RT_FLAG_COUNT_WORK: u32 = 2;

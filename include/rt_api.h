@@ -144,8 +144,8 @@ typedef struct rt_stats {
     uint64_t camera_samples;
     uint64_t rays_closest;   /* closest-hit queries: primary + scattered */
     uint64_t rays_shadow;    /* shadow (occlusion) queries */
-    uint64_t nodes_visited;  /* RT_FLAG_COUNT_WORK */
-    uint64_t tris_tested;    /* RT_FLAG_COUNT_WORK */
+    uint64_t nodes_visited;  /* RT_FLAG_COUNT_WORK: tree nodes visited, closest-hit and occlusion queries together */
+    uint64_t tris_tested;    /* RT_FLAG_COUNT_WORK: exact triangle tests (tree leaves and the scanned list), both kinds of query */
     uint64_t iterations;     /* wavefront iterations (bounce steps) */
     uint64_t launches_extend, launches_shade, launches_shadow, launches_raygen;
     double ms_total;         /* wall time of the call, device work complete */
@@ -154,6 +154,11 @@ typedef struct rt_stats {
     uint64_t rays_shadow_inline; /* of rays_shadow: answered by the shading kernel itself, never written to the shadow queue */
     uint64_t nodes_carrying;     /* of rays_closest: path nodes that brought the light gathered so far along (16 more bytes read,
                                     and written for their successor), to be added to the pixel once at the path's end */
+    /* RT_FLAG_COUNT_WORK, the split the per-kernel rooflines need: */
+    uint64_t nodes_visited_shadow; /* of nodes_visited: by occlusion queries */
+    uint64_t tris_tested_shadow;   /* of tris_tested: tree-leaf triangles tested by occlusion queries */
+    uint64_t tris_scanned;         /* of tris_tested: tests of the triangles kept outside the tree (rt_scene_info.n_loose),
+                                      which a wave reads through uniform loads, not one address per lane */
 } rt_stats;
 
 typedef struct rt_context rt_context;
@@ -183,12 +188,14 @@ enum { RT_SCENE_BVH_ON_DEVICE = 1 };
 int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *desc, uint32_t flags, rt_scene **out);
 
 typedef struct rt_scene_info {
-    int32_t n_triangles;
-    int32_t n_nodes;       /* per visiting order */
+    int32_t n_triangles;   /* all triangles of the world */
+    int32_t n_nodes;       /* per visiting order; the tree holds n_triangles - n_loose triangles */
     int32_t n_orders;      /* 8 = one link set per direction octant, 1 = a single order */
     int32_t n_top;         /* nodes kept in LDS by the traversal kernels */
     int32_t bvh_on_device; /* built by the GPU builder */
-    int32_t reserved;
+    int32_t n_loose;       /* triangles kept out of the tree: when the triangles outside the big meshes (>= 64 faces) are few
+                              (at most 16), every ray scans them in list order, as hit_list does (src/hitable.rs:44-50), and
+                              only rays that touch a big mesh's box walk the tree; 0 when the tree holds everything */
     double bvh_build_ms;   /* wall time of the build, uploads / downloads included */
 } rt_scene_info;
 int32_t rt_scene_get_info(const rt_scene *scene, rt_scene_info *info);

@@ -27,6 +27,7 @@ MAT_DIFFUSE, MAT_METAL, MAT_DIELECTRIC, MAT_MICROFACET = 0, 1, 2, 3
 LIGHT_POINT, LIGHT_DISK, LIGHT_POLYGON = 0, 1, 2
 SAMPLER_WHITE, SAMPLER_UNIFORM, SAMPLER_JITTERED, SAMPLER_BLUE = 1, 2, 3, 4
 OBJ_TRIANGLE, OBJ_SPHERE, OBJ_CYLINDER, OBJ_MESH = 0, 1, 2, 3
+ACCEL_NAIVE, ACCEL_BOX, ACCEL_BVH = 0, 1, 2
 SHADER_NORMAL, SHADER_WHITTED, SHADER_PATH, SHADER_MIS = 0, 1, 2, 3
 FLAG_TIMING, FLAG_COUNT_WORK = 1, 2
 FLAG_RUSSIAN_ROULETTE, FLAG_COSINE_DIFFUSE = 4, 8  # options the reference does not have (off by default)
@@ -74,7 +75,7 @@ class Params(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_int32), ("n_nodes", C.c_int32), ("n_orders", C.c_int32), ("n_top", C.c_int32),
-                ("bvh_on_device", C.c_int32), ("reserved", C.c_int32), ("bvh_build_ms", C.c_double)]
+                ("bvh_on_device", C.c_int32), ("n_loose", C.c_int32), ("bvh_build_ms", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -82,7 +83,8 @@ class Stats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("iterations", C.c_uint64),
                 ("launches_extend", C.c_uint64), ("launches_shade", C.c_uint64), ("launches_shadow", C.c_uint64),
                 ("launches_raygen", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
-                ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_raygen", C.c_double), ("device_bytes", C.c_uint64), ("rays_shadow_inline", C.c_uint64), ("nodes_carrying", C.c_uint64)]
+                ("ms_shade", C.c_double), ("ms_shadow", C.c_double), ("ms_raygen", C.c_double), ("device_bytes", C.c_uint64), ("rays_shadow_inline", C.c_uint64), ("nodes_carrying", C.c_uint64),
+                ("nodes_visited_shadow", C.c_uint64), ("tris_tested_shadow", C.c_uint64), ("tris_scanned", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -506,48 +506,131 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         if (e_ != hipSuccess) return cleanup_fail(e_, #buf);                                                         \
     } while (0)
 
+    // Boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box),
+    // each the union of its triangles' boxes padded as the BVH pads them: a ray that misses all of them cannot hit a
+    // triangle of a big mesh.  Such rays are kept apart in the queues, and when the triangles outside the big meshes
+    // are few (RT_LOOSE_MAX, default 16; 0 = never) they are kept OUT of the tree: every ray scans them in a loop the
+    // whole wave runs together, and only rays that touch a big mesh's box walk the tree, which then holds the big
+    // meshes alone and is entered with the loose triangles' closest hit as its bound.
+    std::vector<char> in_big((size_t)std::max(d->n_tri, 1), 0); // by position in the triangle array
+    {
+        struct MB { int count; float mn[3], mx[3]; };
+        std::vector<MB> mbs;
+        const bool classify = env_u32("RT_NO_HEAVY", 0) == 0;
+        for (int i = 0; i < d->n_obj && classify; i++) {
+            const rt_object &ob = d->objects[i];
+            if (ob.kind != RT_OBJ_MESH || ob.count < 64) continue;
+            MB mb{ob.count, {1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
+            for (int f = 0; f < ob.count; f++) {
+                const float *v = d->tri_v + 9 * (size_t)(ob.first + f);
+                float mn[3], mx[3], ext = 0.0f, mag = 0.0f;
+                for (int a = 0; a < 3; a++) {
+                    mn[a] = std::min(std::min(v[a], v[3 + a]), v[6 + a]);
+                    mx[a] = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
+                    ext = std::max(ext, mx[a] - mn[a]);
+                    mag = std::max(mag, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
+                }
+                const float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f; // same padding as the BVH leaves
+                for (int a = 0; a < 3; a++) { mb.mn[a] = std::min(mb.mn[a], mn[a] - pad); mb.mx[a] = std::max(mb.mx[a], mx[a] + pad); }
+                in_big[(size_t)(ob.first + f)] = 1;
+            }
+            mbs.push_back(mb);
+        }
+        std::sort(mbs.begin(), mbs.end(), [](const MB &a, const MB &b) { return a.count > b.count; });
+        s->dev.n_heavy = 0;
+        for (size_t i = 0; i < mbs.size(); i++) {
+            int k = (int)std::min<size_t>(i, RT_MAX_HEAVY - 1);
+            if ((int)i < RT_MAX_HEAVY) {
+                for (int a = 0; a < 3; a++) { s->dev.heavy_min[k][a] = mbs[i].mn[a]; s->dev.heavy_max[k][a] = mbs[i].mx[a]; }
+                s->dev.n_heavy = k + 1;
+            } else {
+                for (int a = 0; a < 3; a++) {
+                    s->dev.heavy_min[k][a] = std::min(s->dev.heavy_min[k][a], mbs[i].mn[a]);
+                    s->dev.heavy_max[k][a] = std::max(s->dev.heavy_max[k][a], mbs[i].mx[a]);
+                }
+            }
+        }
+    }
+    std::vector<int> loose_src; // positions in the triangle array, which is in primitive-id order
+    for (int i = 0; i < d->n_tri; i++) if (!in_big[(size_t)i]) loose_src.push_back(i);
+    const size_t loose_max = env_u32_allow_zero("RT_LOOSE_MAX", 16);
+    const bool use_loose = loose_max > 0 && loose_src.size() <= loose_max;
+    // the triangles the tree is built over: all of them, or the big meshes' when the others are scanned
+    std::vector<float> sub_v;
+    std::vector<int32_t> sub_prim, sub_mat;
+    const float *bvh_v = d->tri_v;
+    const int32_t *bvh_prim = tri_prim.data(), *bvh_mat = d->tri_mat;
+    int n_bvh = d->n_tri;
+    if (use_loose && !loose_src.empty()) {
+        n_bvh = d->n_tri - (int)loose_src.size();
+        sub_v.reserve(9 * (size_t)n_bvh); sub_prim.reserve((size_t)n_bvh); sub_mat.reserve((size_t)n_bvh);
+        for (int i = 0; i < d->n_tri; i++) {
+            if (!in_big[(size_t)i]) continue;
+            sub_v.insert(sub_v.end(), d->tri_v + 9 * (size_t)i, d->tri_v + 9 * (size_t)i + 9);
+            sub_prim.push_back(tri_prim[(size_t)i]);
+            sub_mat.push_back(d->tri_mat[i]);
+        }
+        bvh_v = sub_v.data(); bvh_prim = sub_prim.data(); bvh_mat = sub_mat.data();
+    }
+
     BvhBuild bvh;
     const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 32);
     const bool ordered = env_u32_allow_zero("RT_BVH_ORDERED", 1) != 0;
-    const bool on_device = (flags & RT_SCENE_BVH_ON_DEVICE) != 0 && d->n_tri > 0;
+    const bool on_device = (flags & RT_SCENE_BVH_ON_DEVICE) != 0 && n_bvh > 0;
     const auto t_build = std::chrono::steady_clock::now();
     if (on_device) {
         // BVHTree::build_tree (mesh.rs:225-261) on the GPU: see rt_bvh_device.hip.  2n-1 nodes, one triangle per leaf,
         // no LDS-resident top (the node numbering is the builder's: inner nodes first, then leaves).
-        bvh.n_nodes = 2 * d->n_tri - 1;
+        bvh.n_nodes = 2 * n_bvh - 1;
         bvh.n_orders = ordered ? 8 : 1;
         bvh.n_top = 0;
     } else {
-        build_bvh(d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh);
+        build_bvh(bvh_v, bvh_prim, bvh_mat, n_bvh, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh);
     }
     // the traversal addresses nodes and triangles through 32-bit byte offsets of a buffer descriptor
     if ((unsigned long long)bvh.n_nodes * (unsigned long long)bvh.n_orders * 32ull >= (1ull << 32) || (unsigned long long)d->n_tri * 48ull >= (1ull << 32)) {
         rt_scene_destroy(s);
         return fail(RT_ERR_INVALID, "scene too large: node or triangle array reaches 4 GiB");
     }
+    auto put_record = [&](float *dst, const float *v, int32_t prim_id, int32_t mat_id) { // v0 + id, E1 + material, E2 (geometry.rs:30-31)
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+        std::memcpy(&dst[3], &prim_id, 4);
+        dst[4] = v[3] - v[0]; dst[5] = v[4] - v[1]; dst[6] = v[5] - v[2];
+        std::memcpy(&dst[7], &mat_id, 4);
+        dst[8] = v[6] - v[0]; dst[9] = v[7] - v[1]; dst[10] = v[8] - v[2];
+        dst[11] = 0.0f;
+    };
     if (on_device) {
         hipError_t e = s->nodes.ensure(2 * (size_t)bvh.n_nodes * (size_t)bvh.n_orders);
         if (e == hipSuccess) e = s->cnodes.ensure((size_t)bvh.n_nodes * (size_t)bvh.n_orders);
         if (e == hipSuccess) e = s->tris.ensure(3 * (size_t)d->n_tri);
-        std::vector<uint32_t> order((size_t)d->n_tri);
+        std::vector<uint32_t> order((size_t)n_bvh);
         float qp[6] = {0, 0, 0, 1, 1, 1};
         if (e == hipSuccess)
-            e = build_bvh_device(ctx->stream, d->tri_v, tri_prim.data(), d->tri_mat, d->n_tri, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp);
+            e = build_bvh_device(ctx->stream, bvh_v, bvh_prim, bvh_mat, n_bvh, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp);
         for (int a = 0; a < 3; a++) { bvh.q_lo[a] = qp[a]; bvh.q_scale[a] = qp[3 + a]; }
         if (e != hipSuccess) return cleanup_fail(e, "BVH build on the device");
-        // host copy of the triangle records, in the device's leaf order: the loose list and the primitive -> record table below read it
-        bvh.tris.resize(12 * (size_t)d->n_tri);
-        for (int i = 0; i < d->n_tri; i++) {
+        // host copy of the triangle records, in the device's leaf order: the primitive -> record table below reads it
+        bvh.tris.resize(12 * (size_t)n_bvh);
+        for (int i = 0; i < n_bvh; i++) {
             const uint32_t t = order[(size_t)i];
-            if (t >= (uint32_t)d->n_tri) return cleanup_fail(hipErrorUnknown, "BVH build on the device returned a bad order");
-            const float *v = d->tri_v + 9 * (size_t)t;
-            float *dst = &bvh.tris[12 * (size_t)i];
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
-            std::memcpy(&dst[3], &tri_prim[t], 4);
-            dst[4] = v[3] - v[0]; dst[5] = v[4] - v[1]; dst[6] = v[5] - v[2];
-            std::memcpy(&dst[7], &d->tri_mat[t], 4);
-            dst[8] = v[6] - v[0]; dst[9] = v[7] - v[1]; dst[10] = v[8] - v[2];
-            dst[11] = 0.0f;
+            if (t >= (uint32_t)n_bvh) return cleanup_fail(hipErrorUnknown, "BVH build on the device returned a bad order");
+            put_record(&bvh.tris[12 * (size_t)i], bvh_v + 9 * (size_t)t, bvh_prim[t], bvh_mat[t]);
+        }
+    }
+    // the loose triangles' records follow the tree's, in primitive-id order; no leaf refers to them
+    const size_t loose_first = bvh.tris.size() / 12;
+    if (n_bvh < d->n_tri) {
+        bvh.tris.resize(12 * (size_t)d->n_tri);
+        for (size_t j = 0; j < loose_src.size(); j++) {
+            const int i = loose_src[j];
+            put_record(&bvh.tris[12 * (loose_first + j)], d->tri_v + 9 * (size_t)i, tri_prim[(size_t)i], d->tri_mat[i]);
+        }
+    }
+    if (on_device) {
+        if (n_bvh < d->n_tri) {
+            hipError_t e = hipMemcpy(s->tris.p + 3 * loose_first, &bvh.tris[12 * loose_first], 48 * loose_src.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return cleanup_fail(e, "loose triangle records");
         }
     } else {
         UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
@@ -569,6 +652,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     s->info.bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     s->info.bvh_on_device = on_device ? 1 : 0;
     s->info.n_nodes = bvh.n_nodes; s->info.n_orders = bvh.n_orders; s->info.n_top = bvh.n_top; s->info.n_triangles = d->n_tri;
+    s->info.n_loose = d->n_tri - n_bvh;
     UP(s->sph, d->sph, d->n_sph, float4);
     std::vector<int2> info(d->n_sph);
     for (int i = 0; i < d->n_sph; i++) info[i] = make_int2(d->sph_mat[i], sph_prim[i]);
@@ -586,60 +670,14 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     s->dev.n_nodes = bvh.n_nodes; s->dev.n_top = bvh.n_top; s->dev.n_orders = bvh.n_orders; s->dev.n_tri = d->n_tri; s->dev.n_sph = d->n_sph; s->dev.n_cyl = d->n_cyl;
     s->dev.n_light = d->n_light;
     s->dev.n_mat = d->n_mat; s->dev.n_light_tri = d->n_light_tri;
-    // Boxes around the big meshes (at most RT_MAX_HEAVY, the largest first; further meshes are merged into the last box),
-    // each the union of its triangles' boxes padded as the BVH pads them: a ray that misses all of them cannot hit a
-    // triangle of a big mesh.  Such rays are kept apart in the queues, and when the triangles outside the big meshes
-    // are few (RT_LOOSE_MAX, default 16; 0 = never) they scan those instead of walking the BVH.
     {
-        struct MB { int count; float mn[3], mx[3]; };
-        std::vector<MB> mbs;
-        std::vector<char> in_big(prim > 0 ? prim : 1, 0); // by primitive id
-        const bool classify = env_u32("RT_NO_HEAVY", 0) == 0;
-        for (int i = 0; i < d->n_obj && classify; i++) {
-            const rt_object &ob = d->objects[i];
-            if (ob.kind != RT_OBJ_MESH || ob.count < 64) continue;
-            MB mb{ob.count, {1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
-            for (int f = 0; f < ob.count; f++) {
-                const float *v = d->tri_v + 9 * (size_t)(ob.first + f);
-                float mn[3], mx[3], ext = 0.0f, mag = 0.0f;
-                for (int a = 0; a < 3; a++) {
-                    mn[a] = std::min(std::min(v[a], v[3 + a]), v[6 + a]);
-                    mx[a] = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
-                    ext = std::max(ext, mx[a] - mn[a]);
-                    mag = std::max(mag, std::max(std::fabs(mn[a]), std::fabs(mx[a])));
-                }
-                const float pad = 1e-4f * ext + 1e-5f * mag + 1e-6f; // same padding as the BVH leaves
-                for (int a = 0; a < 3; a++) { mb.mn[a] = std::min(mb.mn[a], mn[a] - pad); mb.mx[a] = std::max(mb.mx[a], mx[a] + pad); }
-                in_big[tri_prim[ob.first + f]] = 1;
-            }
-            mbs.push_back(mb);
-        }
-        std::sort(mbs.begin(), mbs.end(), [](const MB &a, const MB &b) { return a.count > b.count; });
-        s->dev.n_heavy = 0;
-        for (size_t i = 0; i < mbs.size(); i++) {
-            int k = (int)std::min<size_t>(i, RT_MAX_HEAVY - 1);
-            if ((int)i < RT_MAX_HEAVY) {
-                for (int a = 0; a < 3; a++) { s->dev.heavy_min[k][a] = mbs[i].mn[a]; s->dev.heavy_max[k][a] = mbs[i].mx[a]; }
-                s->dev.n_heavy = k + 1;
-            } else {
-                for (int a = 0; a < 3; a++) {
-                    s->dev.heavy_min[k][a] = std::min(s->dev.heavy_min[k][a], mbs[i].mn[a]);
-                    s->dev.heavy_max[k][a] = std::max(s->dev.heavy_max[k][a], mbs[i].mx[a]);
-                }
-            }
-        }
-        // the loose triangles, taken from the BVH's triangle array (records: v0 + prim id, e1 + material, e2)
+        // the loose list: the records appended above, each followed by its index into the triangle array
         std::vector<std::pair<int, int>> by_prim; // (prim id, index into tris)
-        for (int i = 0; i < d->n_tri; i++) {
-            int32_t pid;
-            std::memcpy(&pid, &bvh.tris[12 * (size_t)i + 3], sizeof(pid));
-            if (!in_big[pid]) by_prim.emplace_back(pid, i);
-        }
-        std::sort(by_prim.begin(), by_prim.end());
+        if (use_loose)
+            for (size_t j = 0; j < loose_src.size(); j++) by_prim.emplace_back(tri_prim[(size_t)loose_src[j]], (int)(loose_first + j));
         std::vector<float> loose;
         s->dev.n_loose = -1;
-        const size_t loose_max = env_u32_allow_zero("RT_LOOSE_MAX", 16);
-        if (loose_max > 0 && by_prim.size() <= loose_max) {
+        if (use_loose) {
             s->dev.n_loose = (int32_t)by_prim.size();
             // Scale of everything a ray's end points can be: rays start on surfaces and end on lights.
             double scale = 0.0;
@@ -688,8 +726,11 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         UP(s->tri_of_prim, tri_of_prim.data(), tri_of_prim.size(), int32_t);
         s->dev.tri_of_prim = s->tri_of_prim.p;
         s->dev.deferred = env_u32_allow_zero("RT_DEFERRED", 1) != 0 ? 1 : 0;
-        s->dev.walk_span = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_SPAN", 4));
-        s->dev.walk_refill = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_REFILL", 32));
+        s->dev.walk_span = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_SPAN", 8));
+        s->dev.walk_refill = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_REFILL", 48));
+        s->dev.walk_pairs = env_u32_allow_zero("RT_WALK_PAIRS", 1) != 0 ? 1 : 0;
+        s->dev.walk_batch = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_BATCH", 64));
+        s->dev.walk_batch_any = (int32_t)std::min<uint32_t>(64u, env_u32("RT_WALK_BATCH_ANY", 64));
         s->dev.inline_shadow = (int32_t)env_u32_allow_zero("RT_INLINE_SHADOW", 1); // 0 never, 1 when it pays (see the render loop), 2 always
     }
 #undef UP
@@ -885,8 +926,11 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         st.rays_closest = c.rays_closest;
         st.rays_shadow = c.rays_shadow;
         st.rays_shadow_inline = c.rays_shadow_inline;
-        st.nodes_visited = c.nodes;
-        st.tris_tested = c.tris;
+        st.nodes_visited = c.nodes + c.nodes_sh;
+        st.tris_tested = c.tris + c.tris_sh + c.scanned;
+        st.nodes_visited_shadow = c.nodes_sh;
+        st.tris_tested_shadow = c.tris_sh;
+        st.tris_scanned = c.scanned;
         if ((p->flags & RT_FLAG_COUNT_WORK) && getenv("RT_DUMP_HIST")) { // development aid: distribution of closest-hit walk lengths
             std::fprintf(stderr, "[rt] closest-hit walks: bucket b = visited nodes in [2^(b-1), 2^b)\n[rt] rays :");
             for (int b = 0; b < 16; b++) std::fprintf(stderr, " %llu", c.hist_ray[b]);

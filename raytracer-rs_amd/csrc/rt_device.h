@@ -154,6 +154,8 @@ struct DevScene {
     int32_t deferred;
     int32_t walk_span; // ... and a wave may own up to 64 * walk_span consecutive rays of a heavy segment
     int32_t walk_refill; // lanes that must be out of work before the wave retires their rays and hands out new ones
+    int32_t walk_pairs;  // a step of that walk fetches a node and its successor together
+    int32_t walk_batch, walk_batch_any; // queued leaves that trigger the exact tests: closest hit / occlusion query
     int32_t carry_in, carry_out; // the nodes read / the nodes written carry the light their path has gathered (NodeQueue::l)
     const int32_t *tri_of_prim; // primitive id -> index into tris (-1 for spheres and cylinders)
     float heavy_min[4][3];
@@ -435,7 +437,8 @@ struct WaveWalkLds {
     float4 ray_a[64];             // o.xyz, d.x
     float2 ray_b[64];             // d.y, d.z
     unsigned long long best[64];  // closest hit: key of the best hit so far; occlusion query: 0 once a hit is known
-    uint2 q[128];                 // ring of (packed leaf, owner lane)
+    static constexpr uint32_t RING = 256u;
+    uint2 q[RING];                // ring of (packed leaf, owner lane): a step adds at most 128 entries to at most 63
 };
 
 __device__ __forceinline__ uint32_t float_order_key(float t) { // monotonic float -> uint
@@ -446,8 +449,31 @@ __device__ __forceinline__ float float_from_order_key(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
 }
 // wave-uniform values kept in scalar registers: tells the compiler what the control flow of the walk relies on
+// (integers only: a condition computed from such integers is uniform by itself, and forcing it through a lane read
+// costs a v_cndmask + v_readfirstlane pair per use)
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+// max / min of values that are never signalling NaNs (results of arithmetic): one instruction each, without the
+// canonicalising v_max x, x the compiler puts in front of fmaxf / fminf operands.  A quiet NaN operand is dropped.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -459,7 +485,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // refilled sc.walk_refill at a time (retiring and starting a ray costs the whole wave about 150 instructions) or when
 // nothing is left to do.
 //
-// Client (one per kernel):  bool fetch(uint32_t k, F3 *o, F3 *d)  loads ray k; false = already decided, no walk
+// Client (one per kernel):  bool fetch(uint32_t k, F3 *o, F3 *d, TriHit *init)  loads ray k; false = already decided, no walk.
+//                               *init (preset to "none") may receive a hit found outside the tree (the loose triangles):
+//                               the walk starts with it as its best hit, so boxes behind it are never entered
 //                           void done(uint32_t k, F3 o, F3 d, const TriHit &h)   closest hit: h.prim (-1 = none), h.t;
 //                                                                                 occlusion query: h.tri >= 0 = occluded
 // Every lane of the wave must call walk_range; `wl` is the calling wave's own area.
@@ -472,6 +500,8 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
     const bool presorted = sc.n_orders == 8;
+    const float t_min_v = t_min;
+    const bool pairs = sc.walk_pairs != 0;
 
     // per-ray state of the lane
     uint32_t my_k = NONE;
@@ -485,55 +515,70 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
     uint32_t next = 0;            // rays of the range handed out so far (wave-uniform)
     uint32_t head = 0, count = 0; // queue: absolute position of its first entry, entries (wave-uniform)
     const uint32_t refill = uni((uint32_t)sc.walk_refill);
+    const uint32_t batch = uni((uint32_t)(ANY_HIT ? sc.walk_batch_any : sc.walk_batch)); // queued leaves that trigger their tests (<= 64)
     first = uni(first);
     total = uni(total);
     for (;;) {
         // Lanes without work are looked after when enough of them have gathered: their queued leaves are tested at once
         // (even fewer than 64), which makes their results final, and they take new rays.
         const uint32_t n_walk = uni((uint32_t)__popcll(__ballot(node >= 0)));
-        const bool starving = uni(next < total && n_walk + refill <= 64u);
-        if (uni(n_walk != 0u && count < 64u && !starving)) {
-            // one step of the walk for every lane that has a node; leaves are queued, not tested
-            int leaf = -1;
-            if (node >= 0) {
-                const u32x4 nd = load16(node_r, g_base + (uint32_t)node * 16u);
+        const bool starving = next < total && n_walk + refill <= 64u;
+        if (n_walk != 0u && count < batch && !starving) {
+            // One step of the walk for every lane that has a node; leaves are queued, not tested.  The walk waits for one
+            // memory round trip per step, and in depth-first order more than half of all steps go on with the very next
+            // node (the first child of a box that was hit, the successor of a leaf): so a step fetches the node AND its
+            // successor together, and takes the successor in the same step when that is where the walk goes.
+            auto test_node = [&](const u32x4 nd, int at, int *leaf) -> int { // box test of node `at`; returns the node to go on with
                 if (COUNT) (*n_nodes)++;
                 const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(nd.x & 0xFFFFu), (float)(nd.x >> 16)}, ix2, ox2);
                 const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(nd.y & 0xFFFFu), (float)(nd.y >> 16)}, iy2, oy2);
                 const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(nd.z & 0xFFFFu), (float)(nd.z >> 16)}, iz2, oz2);
                 float tn, tf;
                 if (presorted) { // the node array of the ray's octant holds (entry plane, exit plane) per axis
-                    tn = fmaxf(__builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x), t_min);
-                    tf = fminf(__builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y), cull_t);
+                    tn = max3_raw(tx.x, ty.x, max_raw(tz.x, t_min_v));
+                    tf = min3_raw(tx.y, ty.y, min_raw(tz.y, cull_t));
                 } else {
                     tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
                     tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
                 }
                 const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
                 const bool is_leaf = (int)nd.w < 0;
-                leaf = (inside && is_leaf) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
+                *leaf = (inside && is_leaf) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
                 // depth-first order: the first child of an inner node and the successor of a leaf are the next node
-                const uint32_t nxt = (inside || is_leaf) ? (uint32_t)node + 1u : nd.w;
-                node = nxt < (uint32_t)sc.n_nodes ? (int)nxt : -1;
-            }
-            const unsigned long long m = __ballot(leaf >= 0);
-            if (m != 0ull) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (leaf >= 0) {
-                    last_pos = head + count + rank;
-                    pushed = true;
-                    wl.q[last_pos & 127u] = make_uint2((uint32_t)leaf, lane);
+                const uint32_t nxt = (inside || is_leaf) ? (uint32_t)at + 1u : nd.w;
+                return nxt < (uint32_t)sc.n_nodes ? (int)nxt : -1;
+            };
+            auto push_leaves = [&](int leaf) { // every lane of the wave calls it
+                const unsigned long long m = __ballot(leaf >= 0);
+                if (m != 0ull) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (leaf >= 0) {
+                        last_pos = head + count + rank;
+                        pushed = true;
+                        wl.q[last_pos & (WaveWalkLds::RING - 1u)] = make_uint2((uint32_t)leaf, lane);
+                    }
+                    count = uni(count + (uint32_t)__popcll(m));
                 }
-                count = uni(count + (uint32_t)__popcll(m));
+            };
+            int leaf = -1, leaf1 = -1;
+            if (node >= 0) {
+                const int at = node;
+                const u32x4 nd = load16(node_r, g_base + (uint32_t)at * 16u);
+                u32x4 nd1 = u32x4{0u, 0u, 0u, 0u};
+                if (pairs) nd1 = load16(node_r, g_base + (uint32_t)at * 16u + 16u); // (past the end of the array: zeros, never used)
+                node = test_node(nd, at, &leaf);
+                if (pairs && node == at + 1) node = test_node(nd1, at + 1, &leaf1);
             }
+            push_leaves(leaf);
+            if (pairs) push_leaves(leaf1); // at most 63 + 64 + 64 entries: the ring holds 256
             continue;
         }
-        if (uni(count > 0u)) {
+        if (count > 0u) {
         // the exact tests of up to 64 queued leaves, one per lane
         wave_lds_fence();
         const uint32_t n = uni(min(count, 64u));
         if (lane < n) {
-            const uint2 e = wl.q[(head + lane) & 127u];
+            const uint2 e = wl.q[(head + lane) & (WaveWalkLds::RING - 1u)];
             const uint32_t owner = e.y;
             const unsigned long long seen = wl.best[owner];
             if (!ANY_HIT || seen != 0ull) {
@@ -575,8 +620,8 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
         // step: a lane's result becomes final when its walk is over and the queue has moved past its last leaf.
         const bool fin = my_k != NONE && node < 0 && (!pushed || (int32_t)(head - last_pos) > 0);
         const uint32_t n_fin = uni((uint32_t)__popcll(__ballot(fin))), n_idle = uni((uint32_t)__popcll(__ballot(my_k == NONE)));
-        const bool drained = uni(count == 0u && __ballot(node >= 0) == 0ull);
-        if (uni(drained || (next < total && n_fin + n_idle >= refill))) {
+        const bool drained = count == 0u && __ballot(node >= 0) == 0ull;
+        if (drained || (next < total && n_fin + n_idle >= refill)) {
             if (fin) {
                 const unsigned long long r = wl.best[lane];
                 const float4 ra = wl.ray_a[lane];
@@ -597,7 +642,10 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
             if (my_k == NONE && rank < remaining) {
                 my_k = first + next + rank;
                 F3 o, d;
-                const bool walk = client.fetch(my_k, &o, &d);
+                TriHit init{t_max, -1, -1};
+                const bool walk = client.fetch(my_k, &o, &d, &init);
+                const unsigned long long k_init = (ANY_HIT || init.prim < 0) ? key0
+                    : (((unsigned long long)float_order_key(init.t) << 32) | (unsigned long long)(uint32_t)(0x7FFFFFFF - init.prim));
                 // box tests only cull (padded boxes, quantised outwards, widened exit): distance to the plane of grid
                 // coordinate q along x = q * (q_scale.x / d.x) + (q_lo.x - o.x) / d.x, one packed multiply-add per axis
                 const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z);
@@ -611,14 +659,14 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 g_base = octant * (uint32_t)sc.n_nodes * 16u;
                 wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
                 wl.ray_b[lane] = make_float2(d.y, d.z);
-                wl.best[lane] = (ANY_HIT && !walk) ? 0ull : key0;
-                cull_t = t_max;
+                wl.best[lane] = (ANY_HIT && !walk) ? 0ull : k_init;
+                cull_t = ANY_HIT ? t_max : init.t;
                 node = (walk && sc.n_nodes > 0) ? 0 : -1;
                 pushed = false;
             }
             next = uni(next + min((uint32_t)__popcll(free_m), remaining));
             wave_lds_fence();
-            if (uni(drained && __ballot(my_k != NONE) == 0ull)) break; // nothing in flight, nothing left to hand out
+            if (drained && __ballot(my_k != NONE) == 0ull) break; // nothing in flight, nothing left to hand out
         }
     }
 }
@@ -626,11 +674,11 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
 // The loose triangles, one after the other, for a ray that misses the boxes of all big meshes.  The loop is the same for
 // every lane of the wave (no divergent walk) and the triangle data is uniform, so the loads are scalar.
 template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_tris) {
+__device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_scan) {
     TriHit best{t_max, -1, -1};
     auto test = [&](int k) { // exact test of loose triangle k; true = an occlusion query is answered
         const float4 a = sc.loose[3 * k], b = sc.loose[3 * k + 1], c = sc.loose[3 * k + 2];
-        if (COUNT) (*n_tris)++;
+        if (COUNT) (*n_scan)++;
         float t;
         if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
             const int prim = __float_as_int(a.w);
@@ -676,13 +724,22 @@ __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d,
     return best;
 }
 
-// world.objects.hit (hitable.rs:35-62): triangles through the BVH, then spheres and cylinders in order.  A sphere or
-// cylinder needs t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.
-template <bool COUNT, bool USE_LDS = false, bool POSTPONE = false, bool LOOSE = false>
+// world.objects.hit (hitable.rs:35-62): triangles, then spheres and cylinders in order.  A sphere or cylinder needs
+// t < closest (geometry.rs:91,148), so a triangle at the same t wins, as in the reference's scan.  Triangles: when the
+// loose list is in use (n_loose >= 0) the tree holds the big meshes only, so the loose triangles are scanned first and
+// the walk starts with their closest hit as its bound; LOOSE_ONLY: the ray is known to miss every big mesh's box.
+template <bool COUNT, bool USE_LDS = false, bool POSTPONE = false, bool LOOSE_ONLY = false>
 __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max, float *t_out,
-                                          int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris) {
-    TriHit th = LOOSE ? loose_traverse<false, COUNT>(sc, o, d, t_min, t_max, n_tris)
-                      : bvh_traverse<false, COUNT, USE_LDS, POSTPONE>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
+                                          int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *n_scan = nullptr) {
+    TriHit th{t_max, -1, -1};
+    uint32_t scan_local = 0; // (work counting: tests of the scanned list go to n_scan, tests of tree leaves to n_tris)
+    if (LOOSE_ONLY || sc.n_loose >= 0) th = loose_traverse<false, COUNT>(sc, o, d, t_min, t_max, &scan_local);
+    if (COUNT && n_scan) *n_scan += scan_local;
+    if (!LOOSE_ONLY) {
+        // a tree triangle at exactly the loose hit's distance is still accepted (geometry.rs:53) and wins with the larger id
+        const TriHit tb = bvh_traverse<false, COUNT, USE_LDS, POSTPONE>(sc, lds_nodes, o, d, t_min, th.t, n_nodes, n_tris);
+        if (tb.tri >= 0 && (tb.t < th.t || tb.prim > th.prim)) th = tb;
+    }
     float closest = th.t;
     int code = th.tri >= 0 ? hit_code(HIT_KIND_TRI, th.tri) : HIT_NONE;
     int prim = th.prim;
@@ -701,9 +758,9 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
 }
 
 // occlusion query: world.hit(r, T_MIN, 1 - T_MIN).is_some() (light.rs:74,170,200,320)
-template <bool COUNT, bool USE_LDS = false, bool LOOSE = false, class SC = DevScene>
+template <bool COUNT, bool USE_LDS = false, bool LOOSE_ONLY = false, class SC = DevScene>
 __device__ __forceinline__ bool world_occluded(const SC &sc, const float4 *lds_nodes, F3 o, F3 d, float t_min, float t_max,
-                                               uint32_t *n_nodes, uint32_t *n_tris) {
+                                               uint32_t *n_nodes, uint32_t *n_tris, uint32_t *n_scan = nullptr) {
     for (int i = 0; i < sc.n_sph; i++) {
         float t;
         if (sph_hit(sc.sph[i], o, d, t_min, t_max, &t)) return true;
@@ -713,9 +770,13 @@ __device__ __forceinline__ bool world_occluded(const SC &sc, const float4 *lds_n
         int kind;
         if (cyl_hit(sc.cyl + 5 * i, o, d, t_min, t_max, &t, &kind)) return true;
     }
-    TriHit th = LOOSE ? loose_traverse<true, COUNT>(sc, o, d, t_min, t_max, n_tris)
-                      : bvh_traverse<true, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris);
-    return th.tri >= 0;
+    const DevScene &g = sc;
+    uint32_t scan_local = 0;
+    const bool hit_loose = (LOOSE_ONLY || g.n_loose >= 0) && loose_traverse<true, COUNT>(sc, o, d, t_min, t_max, &scan_local).tri >= 0;
+    if (COUNT && n_scan) *n_scan += scan_local;
+    if (hit_loose) return true;
+    if (LOOSE_ONLY) return false;
+    return bvh_traverse<true, COUNT, USE_LDS>(sc, lds_nodes, o, d, t_min, t_max, n_nodes, n_tris).tri >= 0;
 }
 
 // ------------------------------------------------------------------------------------------------ lights

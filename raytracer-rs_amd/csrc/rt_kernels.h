@@ -60,6 +60,9 @@ struct CtlHead {
     unsigned long long total;  // all camera candidates of this render call
     unsigned long long rays_closest, rays_shadow, cam_samples, nodes, tris;
     unsigned long long rays_shadow_inline; // of rays_shadow: answered inside k_shade
+    // work-counting launches: nodes / tris = tree nodes visited and leaf triangles tested by closest-hit rays, nodes_sh /
+    // tris_sh by occlusion queries, scanned = exact tests of the list of triangles kept outside the tree (both kinds)
+    unsigned long long nodes_sh, tris_sh, scanned;
     // work-counting launches only: closest-hit rays / waves by floor(log2(visited nodes)) + 1 (bucket 0 = none), and the
     // sum over waves of the largest count among their lanes (the walk length the wave actually pays for)
     unsigned long long hist_ray[16], hist_wave[16], wave_steps, wave_tri_iters;

@@ -13,6 +13,8 @@
 
 #include "rt_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace rtd {
@@ -308,10 +310,14 @@ struct ExtendClient {
     const NodeQueue &in;
     float2 *hit;
     uint32_t base; // first slot of the segment
-    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d) const {
+    mutable uint32_t scanned = 0; // exact tests of the scanned list (work counting)
+    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d, TriHit *init) const {
         const float4 a = in.a[base + k], b = in.b[base + k];
         *o = f3(a.x, a.y, a.z);
         *d = f3(a.w, b.x, b.y);
+        // the triangles outside the big meshes are not in the tree when the loose list is in use: scanned here, and the
+        // walk starts with their closest hit (in a room: the wall behind the mesh) as its bound
+        if (sc.n_loose >= 0) *init = loose_traverse<false, true>(sc, *o, *d, rc.t_min, rc.t_max, &scanned);
         return true;
     }
     // world.objects.hit (hitable.rs:35-62) once the triangles are done: spheres and cylinders need t < closest
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
         if (COUNT) {
             atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
             atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+            atomicAdd(&ctl->h.scanned, (unsigned long long)client.scanned);
         }
         return;
     }
@@ -368,13 +375,14 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     float t_obj;
     int code, prim;
-    uint32_t nn = 0, nt = 0;
+    uint32_t nn = 0, nt = 0, ns = 0;
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
-    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
-    else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
-    else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt);
+    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
+    else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
+    else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
     hit[i] = make_float2(t_obj, __int_as_float(code));
     if (COUNT) {
+        atomicAdd(&ctl->h.scanned, (unsigned long long)ns);
         atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
         atomicAdd(&ctl->h.tris, (unsigned long long)(nt & 0xFFFFu));
         atomicAdd(&ctl->h.wave_tri_iters, (unsigned long long)(nt >> 16));
@@ -907,8 +915,9 @@ struct ShadowClient {
     float *planes;
     uint32_t n_pixels;
     uint32_t base; // first slot of the segment
+    mutable uint32_t scanned = 0; // exact tests of the scanned list (work counting)
     // world.hit(r, T_MIN, 1 - T_MIN): spheres and cylinders first; false = already occluded, no walk
-    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d) const {
+    __device__ __forceinline__ bool fetch(uint32_t k, F3 *o, F3 *d, TriHit *) const {
         const float4 a = sh.a[base + k], b = sh.b[base + k];
         *o = f3(a.x, a.y, a.z);
         *d = f3(a.w, b.x, b.y);
@@ -922,6 +931,7 @@ struct ShadowClient {
             int kind;
             occ = cyl_hit(sc.cyl + 5 * i, *o, *d, rc.t_min, 1.0f - rc.t_min, &t, &kind);
         }
+        if (!occ && sc.n_loose >= 0) occ = loose_traverse<true, true>(sc, *o, *d, rc.t_min, 1.0f - rc.t_min, &scanned).tri >= 0; // not in the tree
         return !occ;
     }
     __device__ __forceinline__ void done(uint32_t k, F3, F3, const TriHit &h) const {
@@ -949,8 +959,9 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
         uint32_t nn = 0, nt = 0;
         walk_range<true, COUNT>(sc, areas[wave], client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
         if (COUNT) {
-            atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
-            atomicAdd(&ctl->h.tris, (unsigned long long)nt);
+            atomicAdd(&ctl->h.nodes_sh, (unsigned long long)nn);
+            atomicAdd(&ctl->h.tris_sh, (unsigned long long)nt);
+            atomicAdd(&ctl->h.scanned, (unsigned long long)client.scanned);
         }
         return;
     }
@@ -965,13 +976,14 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
     if (il >= n) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
-    uint32_t nn = 0, nt = 0;
-    const bool occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt)
-                           : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+    uint32_t nn = 0, nt = 0, ns = 0;
+    const bool occ = loose ? world_occluded<COUNT, false, true>(sc, nullptr, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt, &ns)
+                           : world_occluded<COUNT, USE_LDS>(sc, lds_nodes, o, d, rc.t_min, 1.0f - rc.t_min, &nn, &nt, &ns);
     if (!occ) add_pixel(planes, n_pixels, __float_as_uint(c.y), f3(b.z, b.w, c.x));
     if (COUNT) {
-        atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
-        atomicAdd(&ctl->h.tris, (unsigned long long)(nt & 0xFFFFu));
+        atomicAdd(&ctl->h.nodes_sh, (unsigned long long)nn);
+        atomicAdd(&ctl->h.tris_sh, (unsigned long long)(nt & 0xFFFFu));
+        atomicAdd(&ctl->h.scanned, (unsigned long long)ns);
     }
 }
 
@@ -1117,7 +1129,12 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
 // dynamic LDS of the traversal kernels: the top of the tree (when cached) + one queue area per wave
-static inline size_t lds_bytes(const DevScene &sc, bool use_lds) { return wave_area_offset(sc, use_lds) + (BLOCK / 64) * sizeof(WaveWalkLds); }
+static inline size_t lds_bytes(const DevScene &sc, bool use_lds) {
+    size_t need = wave_area_offset(sc, use_lds) + (BLOCK / 64) * sizeof(WaveWalkLds);
+    // experiment: a larger request lowers the number of resident workgroups per CU
+    if (const char *v = std::getenv("RT_WALK_LDS_KB")) need = std::max(need, (size_t)std::atoi(v) * 1024u);
+    return need;
+}
 
 void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
 

@@ -355,6 +355,48 @@ def test_tie_backface_and_degenerate_triangles(rt, orc, gpu_ctx):
     ds.close()
 
 
+@pytest.mark.parametrize("deferred", ["1", "0"])
+def test_ties_between_scanned_triangles_and_a_mesh_in_the_tree(rt, orc, gpu_ctx, monkeypatch, deferred):
+    """The few triangles outside the big meshes are scanned and only the big meshes are walked; the walk starts with the
+    scan's closest hit.  Exact duplicates of mesh faces listed before the mesh lose the tie, duplicates listed after it
+    win (src/hitable.rs:44-50 with src/geometry.rs:53), a single triangle in front hides the mesh, one behind does not —
+    for closest hits, shading and occlusion queries, with the wave-cooperative walk and the plain one."""
+    monkeypatch.setenv("RT_DEFERRED", deferred)
+    n = 8  # a wall of n x n x 2 = 128 faces at z = -3, facing the camera: a "big" mesh (>= 64 faces)
+    xs = np.linspace(-1.0, 1.0, n + 1, dtype=np.float32)
+    wall = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = (xs[i], xs[j], -3.0), (xs[i + 1], xs[j], -3.0), (xs[i + 1], xs[j + 1], -3.0), (xs[i], xs[j + 1], -3.0)
+            wall += [[*a, *b, *c], [*a, *c, *d]]
+    before = [wall[5], wall[40]]                      # duplicates earlier in the world list: the mesh's faces win
+    after = [wall[77], wall[100]]                     # duplicates later in the list: they win
+    front = [[-0.9, -0.9, -2.5, -0.4, -0.9, -2.5, -0.65, -0.4, -2.5]]  # hides a part of the wall and shadows it
+    behind = [[0.2, 0.2, -3.5, 0.9, 0.2, -3.5, 0.55, 0.9, -3.5]]       # never seen
+    floor = [[-2, -1, 0, 2, -1, 0, 2, -1, -4], [-2, -1, 0, 2, -1, -4, -2, -1, -4]]
+    tri_v = np.array(before + floor + wall + after + front + behind, np.float32)
+    nb, nw = len(before) + len(floor), len(wall)
+    objects = [rt.Object(rt.OBJ_TRIANGLE, i, 1, 0) for i in range(nb)] + [rt.Object(rt.OBJ_MESH, nb, nw, rt.ACCEL_BVH)]
+    objects += [rt.Object(rt.OBJ_TRIANGLE, nb + nw + i, 1, 0) for i in range(len(after) + 2)]
+    sc = rt.NumpyScene(tri_v=tri_v, tri_mat=[0] * len(tri_v), mats=[rt.diffuse(0.8, 0.7, 0.6)], objects=objects,
+                       lights=[rt.Light(rt.LIGHT_POINT, (0.3, 0.8, -1.0), 0, (5, 5, 5), 0, 0, 1)])
+    ds = rt.DeviceScene(gpu_ctx, sc.desc, sc)
+    assert ds.info.n_loose == len(tri_v) - nw and ds.info.n_nodes > 0
+    osc = orc.OracleScene(sc.desc, 0, sc)
+    cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
+    for shader in (rt.SHADER_MIS, rt.SHADER_WHITTED):
+        p = rt.default_params(96, 96, 2, shader=shader, pixel_sampler=rt.SAMPLER_WHITE)
+        gp, gt = ds.primary_hits(cam, p)
+        cp, ct = osc.primary_hits(cam, p)
+        assert np.array_equal(gp, cp) and np.array_equal(gt, ct)
+        seen = set(np.unique(gp))
+        assert {nb + 5, nb + 40, nb + nw, nb + nw + 1, nb + nw + 2} <= seen and not ({0, 1, nb + 77, nb + 100, nb + nw + 3} & seen)
+        ga, _ = ds.render(cam, p)
+        ca, _ = osc.render(cam, p)
+        assert_radiance_close(ga, ca)
+    ds.close()
+
+
 @pytest.mark.parametrize("shader_name", ["SHADER_WHITTED", "SHADER_MIS"])
 def test_occluders_next_to_the_ends_of_shadow_segments(rt, orc, gpu_ctx, shader_name):
     """Occlusion queries over a short triangle list skip a triangle when a whole wave's segments lie clearly on one side
@@ -704,17 +746,23 @@ def test_gpu_light_scene_matches_the_reference_render(rt, gpu_ctx, golden_dir):
 
 
 # ---- the acceleration structure built on the GPU ------------------------------------------------------------------------
+@pytest.mark.parametrize("loose_max", ["16", "0"])
 @pytest.mark.parametrize("scene,W,H", [("utah", 160, 90), ("miku", 160, 90), ("composite", 96, 54), ("blue_noise_test", 64, 64), ("head", 48, 48)])
-def test_device_built_bvh_gives_the_same_hits_and_image(rt, orc, gpu_ctx, scene, W, H):
+def test_device_built_bvh_gives_the_same_hits_and_image(rt, orc, gpu_ctx, monkeypatch, scene, W, H, loose_max):
     """rt_scene_create_ex(RT_SCENE_BVH_ON_DEVICE) — BVHTree::build_tree (src/mesh.rs:225-261) on the GPU: another tree
     (one triangle per leaf, 2n-1 nodes), the same closest hits as the host-built tree and the oracle, bit for bit, and
-    the same image."""
+    the same image.  With RT_LOOSE_MAX=0 the tree holds every triangle; by default the few triangles outside the big
+    meshes stay out of it (the head scene then has no tree at all)."""
+    monkeypatch.setenv("RT_LOOSE_MAX", loose_max)
     hs = rt.HostScene(scene, W / H)
     host = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=False)
     dev = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=True)
     n = hs.desc.n_tri
-    assert (host.info.bvh_on_device, dev.info.bvh_on_device) == (0, 1)
-    assert dev.info.n_triangles == n and dev.info.n_nodes == 2 * n - 1 and dev.info.n_orders == 8 and dev.info.n_top == 0
+    n_tree = n - dev.info.n_loose  # the few triangles outside the big meshes are scanned, not walked
+    assert dev.info.n_loose == host.info.n_loose and (loose_max != "0" or n_tree == n)
+    assert (host.info.bvh_on_device, dev.info.bvh_on_device) == (0, 1 if n_tree > 0 else 0)
+    assert dev.info.n_triangles == n and dev.info.n_nodes == max(0, 2 * n_tree - 1) and dev.info.n_top == 0
+    assert dev.info.n_orders == 8 or n_tree == 0
     assert dev.info.bvh_build_ms > 0 and host.info.n_nodes <= dev.info.n_nodes
     p = rt.default_params(W, H, 2, seed=4)
     hp, ht = host.primary_hits(hs.camera, p)
@@ -734,9 +782,10 @@ def test_device_built_bvh_gives_the_same_hits_and_image(rt, orc, gpu_ctx, scene,
     dev.close()
 
 
-def test_device_built_bvh_edge_cases(rt, orc, gpu_ctx):
+def test_device_built_bvh_edge_cases(rt, orc, gpu_ctx, monkeypatch):
     """One triangle (no inner node), two identical triangles (equal Morton codes; the later one wins the tie), the
     axis-aligned cube (flat boxes), and an empty world."""
+    monkeypatch.setenv("RT_LOOSE_MAX", "0")  # every triangle into the tree: these few would otherwise be scanned
     cam = rt.camera_new((0, 0, 2), (0, 0, -1), (0, 1, 0), 90.0, 1.0)
     tri = [-1, -1, -3, 1, -1, -3, 0, 1, -3]
     cube = rt.load_obj(os.path.join(rt.ASSET_DIR, "cube.obj")) * np.float32(0.2) + np.tile(np.array([-0.3, -0.4, -3.0], np.float32), 3)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ab_env.sh WORKLOAD SPP "ENV=.. ENV=.." ...: bench stage split for each environment setting (run on the GPU box)
+# usage: ab_env.sh WORKLOAD SPP "ENV=.. ENV=.." ...
 wl=$1; spp=$2; shift 2
 for v in "$@"; do
   echo "== $v"

@@ -37,7 +37,7 @@ $(LIBDIR)/librt_host.so: $(PKG)/host/rt_host.cpp $(PKG)/host/rt_host.hpp include
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(PKG)/host/rt_host.cpp
 
 tools/rtcli: tools/rtcli.cpp $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so
-	$(CXX) $(HOSTFLAGS) -o $@ tools/rtcli.cpp -L$(LIBDIR) -lrt_hip -lrt_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+	$(CXX) $(HOSTFLAGS) -pthread -o $@ tools/rtcli.cpp -L$(LIBDIR) -lrt_hip -lrt_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
 # micro-benchmark: peak rate of per-lane (divergent) loads, the roofline of the BVH walk kernels
 tools/ta_rate: tools/ta_rate.hip

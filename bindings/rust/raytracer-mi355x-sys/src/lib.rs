@@ -63,6 +63,10 @@ extern "C" {
                            prim_id: *mut i32, t: *mut f32) -> i32;
     pub fn rt_resolve(accum_rgb: *const f32, n_pixels: i64, spp: i32, out_i32: *mut i32, rgb8: *mut u8) -> i32;
     pub fn rt_resolve_device(ctx: *mut rt_context, accum_dev: *const f32, n_pixels: i64, spp: i32, rgb8_dev: *mut u8) -> i32;
+    pub fn rt_accum_create(ctx: *mut rt_context, width: i32, height: i32, accum_dev_out: *mut *mut f32) -> i32;
+    pub fn rt_accum_destroy(ctx: *mut rt_context, accum_dev: *mut f32) -> i32;
+    pub fn rt_accum_download(ctx: *mut rt_context, accum_dev: *const f32, host_out: *mut f32, n_floats: i64) -> i32;
+    pub fn rt_reduce_accum(ctxs: *const *mut rt_context, n: i32, accum_dev: *const *mut f32, n_floats: i64, root: i32) -> i32;   // RCCL sum over the GPUs of this process
     pub fn rt_context_stream(ctx: *mut rt_context) -> *mut c_void;
     pub fn rt_params_default(p: *mut rt_params, width: i32, height: i32, spp: i32);
     pub fn rt_bvh_build_host(tri_v: *const f32, n_tri: i32, max_top: i32, ordered: i32, nodes_out: *mut f32, tris_out: *mut f32,

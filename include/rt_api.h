@@ -235,6 +235,31 @@ int32_t rt_resolve(const float *accum_rgb, int64_t n_pixels, int32_t spp, int32_
 /* Device-side resolve of a device accumulation buffer into device rgb8 (same arithmetic), on the render stream. */
 int32_t rt_resolve_device(rt_context *ctx, const float *accum_rgb_dev, int64_t n_pixels, int32_t spp, uint8_t *rgb8_dev);
 
+/*
+ * Per-GPU accumulation buffers and their reduction: the multi-GPU form of the pixel x sample loop (src/bin/main.rs:28-52
+ * has one `col` per pixel on one thread; here every GPU sums its share of the samples or tiles of a frame and the sums
+ * meet once).  One context per device, all in ONE process; each context is driven by its own host thread while it
+ * renders (rt_render blocks), any thread may call the reduction afterwards.
+ *
+ * rt_accum_create: a zeroed device buffer of width*height*3 floats on the context's device, to be passed to rt_render with
+ * accum_is_device != 0.  rt_accum_download: copies n_floats floats to host memory.  rt_accum_destroy frees it.
+ */
+int32_t rt_accum_create(rt_context *ctx, int32_t width, int32_t height, float **accum_dev_out);
+int32_t rt_accum_destroy(rt_context *ctx, float *accum_dev);
+int32_t rt_accum_download(rt_context *ctx, const float *accum_dev, float *host_out, int64_t n_floats);
+
+/*
+ * accum_dev[root] += sum of accum_dev[i], i != root (n_floats floats each; accum_dev[i] lives on ctxs[i]'s device; the
+ * other buffers are left as they are).  Buffers on different devices are summed with one RCCL reduce (ncclReduce,
+ * sum, over xGMI; communicators from ncclCommInitAll are created at the first call for a set of devices and kept until
+ * one of those devices' contexts is destroyed);
+ * buffers that share a device (logical shards on one GPU) are added by a kernel first.  RCCL is loaded when first
+ * needed (librccl.so.1; RT_RCCL_LIB overrides the name): RT_ERR_UNSUPPORTED if it is missing.  Tile shards touch
+ * disjoint pixels, so their sum is exact; sample-range shards differ from one GPU's result by float summation order.
+ * All work of the contexts must be complete (rt_render has returned); the call returns with the sum complete.
+ */
+int32_t rt_reduce_accum(rt_context *const *ctxs, int32_t n, float *const *accum_dev, int64_t n_floats, int32_t root);
+
 /* The HIP stream (hipStream_t) all work of this context is enqueued on, for callers that time with events. */
 void *rt_context_stream(rt_context *ctx);
 

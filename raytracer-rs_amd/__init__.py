@@ -367,6 +367,14 @@ def hip_lib() -> C.CDLL:
         lib.rt_resolve.restype = C.c_int32
         lib.rt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         lib.rt_resolve_device.restype = C.c_int32
+        lib.rt_accum_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.rt_accum_create.restype = C.c_int32
+        lib.rt_accum_destroy.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rt_accum_destroy.restype = C.c_int32
+        lib.rt_accum_download.argtypes = [C.c_void_p, C.c_void_p, c_float_p, C.c_int64]
+        lib.rt_accum_download.restype = C.c_int32
+        lib.rt_reduce_accum.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int64, C.c_int32]
+        lib.rt_reduce_accum.restype = C.c_int32
         lib.rt_context_stream.argtypes = [C.c_void_p]
         lib.rt_context_stream.restype = C.c_void_p
         lib.rt_params_default.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32]
@@ -439,6 +447,44 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class DeviceAccum:
+    """rt_accum_create: a zeroed (H, W, 3) float32 sum buffer on a context's device, owned by the library."""
+
+    def __init__(self, ctx: Context, width: int, height: int):
+        self.ctx, self.width, self.height = ctx, width, height
+        self._p = C.c_void_p()
+        _check(hip_lib().rt_accum_create(ctx._h, width, height, C.byref(self._p)))
+
+    @property
+    def ptr(self) -> int:
+        return self._p.value or 0
+
+    def download(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.float32)
+        _check(hip_lib().rt_accum_download(self.ctx._h, self._p, _fp(out), out.size))
+        return out
+
+    def close(self):
+        if self._p and self.ctx._h:
+            hip_lib().rt_accum_destroy(self.ctx._h, self._p)
+        self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reduce_accum_devices(accums, root: int = 0) -> None:
+    """rt_reduce_accum: accums[root] += the other buffers (DeviceAccum objects of one frame size, one per context of this
+    process); RCCL between devices, a kernel between buffers that share a device."""
+    n = len(accums)
+    ctxs = (C.c_void_p * n)(*[a.ctx._h for a in accums])
+    ptrs = (C.c_void_p * n)(*[a._p for a in accums])
+    _check(hip_lib().rt_reduce_accum(ctxs, n, ptrs, accums[0].width * accums[0].height * 3, root))
 
 
 class DeviceScene:

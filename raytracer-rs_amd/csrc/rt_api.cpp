@@ -4,6 +4,8 @@
 #include "../../include/rt_api.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is loaded when rt_reduce_accum first needs it
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -11,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -143,6 +146,8 @@ static unsigned char *g_scratch_ptr[RT_MAX_DEVICES]; // per device; written unde
 static std::mutex g_scratch_mutex;
 
 namespace {
+
+void drop_communicators_of(int device); // RCCL communicators that include the device (defined with rt_reduce_accum)
 
 int set_device(rt_context *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
@@ -371,6 +376,7 @@ int32_t rt_context_destroy(rt_context *ctx) {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    drop_communicators_of(ctx->device); // they were created on this context's stream; a later reduction makes new ones
     for (int k = 0; k < 2; k++) { ctx->qa[k].release(); ctx->qb[k].release(); ctx->qc[k].release(); ctx->ql[k].release(); }
     ctx->hit.release();
     for (int k = 0; k < 2; k++) { ctx->sa[k].release(); ctx->sb[k].release(); ctx->sc2[k].release(); }
@@ -867,8 +873,8 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             }
             // most nodes a segment of each class can hold after ray generation: what it carried in + its share of the
             // raygen workgroups (workgroup b feeds segment b % RT_NSEG_HALF of either class)
-            const uint32_t new_blocks = (c.n_new + 255u) / 256u;
-            const uint32_t fresh = ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * 256u;
+            const uint32_t new_blocks = (c.n_new + RT_RAYGEN_PER_WG - 1u) / RT_RAYGEN_PER_WG;
+            const uint32_t fresh = ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * RT_RAYGEN_PER_WG;
             const uint32_t light_threads = std::min(seg_capacity, c.max_in_light + fresh);
             const uint32_t heavy_threads = s->dev.n_heavy ? std::min(seg_capacity, c.max_in_heavy + fresh) : c.max_in_heavy;
             if (tail_limit && c.n_new == 0 && c.cursor == c.total && c.n_alive <= tail_limit) {
@@ -1135,6 +1141,176 @@ int32_t rt_resolve_device(rt_context *ctx, const float *accum_rgb_dev, int64_t n
     launch_resolve(ctx->stream, accum_rgb_dev, n_pixels, spp, rgb8_dev);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+
+// ---- per-GPU accumulation buffers and their reduction ---------------------------------------------------------------------
+int32_t rt_accum_create(rt_context *ctx, int32_t width, int32_t height, float **out) {
+    if (!ctx || !out || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_accum_create: bad argument");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)width * (size_t)height * 3u * sizeof(float);
+    float *p = nullptr;
+    HIP_TRY_ALLOC(hipMalloc((void **)&p, bytes));
+    hipError_t e = hipMemsetAsync(p, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(RT_ERR_DEVICE, std::string("rt_accum_create: ") + hipGetErrorString(e));
+    }
+    *out = p;
+    return RT_OK;
+}
+
+int32_t rt_accum_destroy(rt_context *ctx, float *accum_dev) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null argument");
+    if (!accum_dev) return RT_OK;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(accum_dev));
+    return RT_OK;
+}
+
+int32_t rt_accum_download(rt_context *ctx, const float *accum_dev, float *host_out, int64_t n_floats) {
+    if (!ctx || !accum_dev || !host_out || n_floats < 0) return fail(RT_ERR_INVALID, "rt_accum_download: bad argument");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host_out, accum_dev, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+// RCCL, resolved at the first reduction over more than one device.  A process that already holds an RCCL (PyTorch's
+// bundled copy has the same soname) gets that one.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string error;
+    bool tried = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // by device list; kept until the process ends
+
+bool load_rccl() { // g_rccl_mutex held
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    std::vector<std::string> names;
+    if (const char *v = std::getenv("RT_RCCL_LIB")) names.push_back(v);
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+    for (const std::string &n : names) {
+        g_rccl.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+        if (const char *e = dlerror()) g_rccl.error = e;
+    }
+    if (!g_rccl.lib) return false;
+    auto sym = [&](const char *name) {
+        void *p = dlsym(g_rccl.lib, name);
+        if (!p) g_rccl.error = std::string("missing symbol ") + name;
+        return p;
+    };
+    g_rccl.comm_init_all = reinterpret_cast<decltype(g_rccl.comm_init_all)>(sym("ncclCommInitAll"));
+    g_rccl.comm_destroy = reinterpret_cast<decltype(g_rccl.comm_destroy)>(sym("ncclCommDestroy"));
+    g_rccl.reduce = reinterpret_cast<decltype(g_rccl.reduce)>(sym("ncclReduce"));
+    g_rccl.group_start = reinterpret_cast<decltype(g_rccl.group_start)>(sym("ncclGroupStart"));
+    g_rccl.group_end = reinterpret_cast<decltype(g_rccl.group_end)>(sym("ncclGroupEnd"));
+    g_rccl.error_string = reinterpret_cast<decltype(g_rccl.error_string)>(sym("ncclGetErrorString"));
+    if (!g_rccl.comm_init_all || !g_rccl.comm_destroy || !g_rccl.reduce || !g_rccl.group_start || !g_rccl.group_end || !g_rccl.error_string) {
+        dlclose(g_rccl.lib);
+        g_rccl.lib = nullptr;
+        return false;
+    }
+    return true;
+}
+
+void drop_communicators_of(int device) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    for (auto it = g_comms.begin(); it != g_comms.end();) {
+        if (std::find(it->first.begin(), it->first.end(), device) == it->first.end()) { ++it; continue; }
+        for (size_t k = 0; k < it->second.size(); k++) {
+            (void)hipSetDevice(it->first[k]);
+            (void)g_rccl.comm_destroy(it->second[k]);
+        }
+        it = g_comms.erase(it);
+    }
+    (void)hipSetDevice(device);
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t rt_reduce_accum(rt_context *const *ctxs, int32_t n, float *const *accum_dev, int64_t n_floats, int32_t root) {
+    if (!ctxs || !accum_dev || n < 1 || root < 0 || root >= n || n_floats < 0) return fail(RT_ERR_INVALID, "rt_reduce_accum: bad argument");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !accum_dev[i]) return fail(RT_ERR_INVALID, "rt_reduce_accum: null context or buffer");
+        for (int j = 0; j < i; j++)
+            if (accum_dev[j] == accum_dev[i]) return fail(RT_ERR_INVALID, "rt_reduce_accum: the same buffer twice");
+    }
+    // 1. buffers that share a device are added into that device's representative (the root's buffer on the root's device)
+    std::vector<int> devices, rep; // distinct devices in order of first appearance, and the index of their representative
+    for (int i = 0; i < n; i++) {
+        size_t k = 0;
+        while (k < devices.size() && devices[k] != ctxs[i]->device) k++;
+        if (k == devices.size()) { devices.push_back(ctxs[i]->device); rep.push_back(i); }
+        if (i == root) rep[k] = root;
+    }
+    for (int i = 0; i < n; i++) {
+        size_t k = 0;
+        while (devices[k] != ctxs[i]->device) k++;
+        if (rep[k] == i) continue;
+        rt_context *rc_ctx = ctxs[rep[k]];
+        int rc = set_device(rc_ctx);
+        if (rc) return rc;
+        launch_accum_add(rc_ctx->stream, accum_dev[rep[k]], accum_dev[i], n_floats);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t k = 0; k < devices.size(); k++) {
+        int rc = set_device(ctxs[rep[k]]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctxs[rep[k]]->stream));
+    }
+    // 2. one RCCL reduce over the distinct devices (a single device goes through RCCL only on request: RT_REDUCE_RCCL_ALWAYS=1)
+    if (devices.size() == 1 && env_u32_allow_zero("RT_REDUCE_RCCL_ALWAYS", 0) == 0) return RT_OK;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!load_rccl()) return fail(RT_ERR_UNSUPPORTED, "rt_reduce_accum: RCCL is not available: " + g_rccl.error);
+    auto nccl_fail = [&](const char *what, ncclResult_t r) { return fail(RT_ERR_DEVICE, std::string(what) + ": " + g_rccl.error_string(r)); };
+    auto it = g_comms.find(devices);
+    if (it == g_comms.end()) {
+        std::vector<ncclComm_t> comms(devices.size());
+        ncclResult_t r = g_rccl.comm_init_all(comms.data(), (int)devices.size(), devices.data());
+        if (r != ncclSuccess) return nccl_fail("ncclCommInitAll", r);
+        it = g_comms.emplace(devices, comms).first;
+    }
+    size_t root_k = 0;
+    while (devices[root_k] != ctxs[root]->device) root_k++;
+    ncclResult_t r = g_rccl.group_start();
+    if (r != ncclSuccess) return nccl_fail("ncclGroupStart", r);
+    for (size_t k = 0; k < devices.size(); k++) {
+        int rc = set_device(ctxs[rep[k]]);
+        if (rc) { (void)g_rccl.group_end(); return rc; }
+        float *buf = accum_dev[rep[k]];
+        r = g_rccl.reduce(buf, buf, (size_t)n_floats, ncclFloat, ncclSum, (int)root_k, it->second[k], ctxs[rep[k]]->stream);
+        if (r != ncclSuccess) { (void)g_rccl.group_end(); return nccl_fail("ncclReduce", r); }
+    }
+    r = g_rccl.group_end();
+    if (r != ncclSuccess) return nccl_fail("ncclGroupEnd", r);
+    for (size_t k = 0; k < devices.size(); k++) {
+        int rc = set_device(ctxs[rep[k]]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctxs[rep[k]]->stream));
+    }
     return RT_OK;
 }
 

@@ -32,6 +32,9 @@ struct ShadowQueue {
 // Segments [0, RT_NSEG/2) hold "light" rays, [RT_NSEG/2, RT_NSEG) "heavy" ones (see DevScene::n_heavy); a producing
 // workgroup b appends to segment (b % (RT_NSEG/2)) of each half; consumers run a (blocks, NSEG) grid, heavy half first.
 #define RT_NSEG 32
+// camera candidates one workgroup / one thread of the ray generation kernel takes (256 threads)
+#define RT_RAYGEN_PER_THREAD 4
+#define RT_RAYGEN_PER_WG (256 * RT_RAYGEN_PER_THREAD)
 #define RT_NSEG_HALF (RT_NSEG / 2)
 
 struct SegCounter {
@@ -102,6 +105,7 @@ void launch_normal_shader(const LaunchCfg &cfg, const DevScene &sc, const Render
 void launch_primary_hits(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, int32_t *prim, float *t);
 void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const float *planes, float *accum_rgb, uint32_t n_pixels);
 void launch_tri_normals(hipStream_t stream, const float4 *tris, int n, float4 *out);
+void launch_accum_add(hipStream_t stream, float *dst, const float *src, int64_t n);
 void launch_resolve(hipStream_t stream, const float *accum_rgb, int64_t n_pixels, int32_t spp, uint8_t *rgb8);
 
 } // namespace rtd

@@ -39,44 +39,6 @@ __device__ __forceinline__ uint32_t wave_append(bool valid, uint32_t *counter) {
     return base + below;
 }
 
-// Six element streams in four groups, one counter per group (a group's streams share one reservation, laid out wave by
-// wave, stream by stream):  group 0 = {0,1} light children   group 1 = {2,3} heavy children
-//                           group 2 = {4}   light shadow ray  group 3 = {5}   heavy shadow ray
-struct BlockAppend {
-    uint32_t wave_cnt[BLOCK / 64][6];
-    uint32_t base[4];
-};
-
-__device__ __forceinline__ void block_append(BlockAppend &sm, const bool (&flag)[6], uint32_t *const (&counter)[4], uint32_t (&slot)[6]) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t below[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const unsigned long long m = __ballot(flag[k]);
-        below[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (lane == 0) sm.wave_cnt[wave][k] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int g = (int)threadIdx.x;
-        const int k0 = g < 2 ? 2 * g : g + 2, k1 = g < 2 ? 2 * g + 1 : g + 2;
-        uint32_t total = 0;
-        for (int w = 0; w < BLOCK / 64; w++) total += sm.wave_cnt[w][k0] + (k1 != k0 ? sm.wave_cnt[w][k1] : 0u);
-        sm.base[g] = total ? atomicAdd(counter[g], total) : 0u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int g = k < 4 ? k >> 1 : k - 2;
-        const int k0 = g < 2 ? 2 * g : g + 2, k1 = g < 2 ? 2 * g + 1 : g + 2;
-        uint32_t off = sm.base[g];
-        for (uint32_t w = 0; w < wave; w++) off += sm.wave_cnt[w][k0] + (k1 != k0 ? sm.wave_cnt[w][k1] : 0u);
-        if (k != k0) off += sm.wave_cnt[wave][k0];
-        slot[k] = off + below[k];
-    }
-    __syncthreads(); // sm may be reused by the next call
-}
-
 // Append of two path nodes (next queue) and one shadow ray (shadow queue) per lane, each light or heavy: four groups
 // (light nodes, heavy nodes, light shadow rays, heavy shadow rays), one counter each in segment `seg_l` of its class.
 // Inside a wave the elements keep lane order (ballot + mbcnt) and a wave's elements are contiguous: a wave of camera rays
@@ -228,7 +190,9 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     uint32_t n_new = 0;
     if (alive < target && remaining > 0) {
         unsigned long long room = target - alive;
-        if (room >= BLOCK) room &= ~(unsigned long long)(BLOCK - 1); // whole workgroups: a wave stays one block of one sample
+        // whole raygen workgroups, or at least whole waves (a wave is one 8x8 block of one sample: k_raygen relies on it;
+        // the total is a multiple of 64 as well)
+        room &= room >= RT_RAYGEN_PER_WG ? ~(unsigned long long)(RT_RAYGEN_PER_WG - 1) : ~63ull;
         n_new = (uint32_t)(remaining < room ? remaining : room);
     }
     const unsigned long long chunk_candidates = (unsigned long long)h.per_sample * h.chunk_samples;
@@ -247,56 +211,96 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
 
 // ---- k_raygen -------------------------------------------------------------------------------------------------------
 // Camera candidates are numbered chunk -> 8x8 pixel block -> sample inside the chunk -> pixel inside the block (see
-// CtlHead).  One wave = one 8x8 block of one sample, one workgroup = four samples of the same block.
+// CtlHead).  One wave = one 8x8 block of one sample; a workgroup takes RT_RAYGEN_PER_WG consecutive candidates, every
+// thread RT_RAYGEN_PER_THREAD of them (the same pixel in consecutive samples while the chunk lasts), and reserves
+// its queue slots ONCE: one returning atomic per class and workgroup and two barriers for 1024 rays.  The rays wait in
+// registers for their slots.
+struct RaygenAppend {
+    uint32_t cnt[2];  // light / heavy rays of the workgroup
+    uint32_t base[2]; // the workgroup's first slot per class
+};
+
 __global__ __launch_bounds__(BLOCK) void k_raygen(DevScene sc, RenderConst rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                                                   uint32_t seg_capacity) {
-    __shared__ BlockAppend sm;
-    const uint32_t g = blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ RaygenAppend sm;
     const uint32_t n_new = ctl->h.n_new;
-    if (blockIdx.x * BLOCK >= n_new) return; // whole workgroup idle
-    bool valid = false;
-    Node n;
-    if (g < n_new) {
-        const uint32_t per_sample = ctl->h.per_sample, n_samples = ctl->h.n_samples, chunk_samples = ctl->h.chunk_samples;
-        uint32_t r = ctl->h.first_rem + g; // < 2^31: the host bounds per_sample * chunk_samples and the refill level
-        uint32_t s0 = ctl->h.first_sample;
-        uint32_t in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
-        while (in_chunk != 0u && r >= per_sample * in_chunk) { // the batch runs over into the next chunk(s)
-            r -= per_sample * in_chunk;
-            s0 += in_chunk;
-            in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
-        }
-        const uint32_t div = 64u * max(in_chunk, 1u);
-        const uint32_t bi = min(r / div, per_sample / 64u - 1u); // in range even if the counters were inconsistent
-        const uint32_t within = r - bi * div;
-        const uint32_t s_rel = s0 + (within >> 6), lane = within & 63u;
-        uint32_t blk = blocks ? (uint32_t)blocks[bi] : bi;
-        int x = (int)((blk % blocks_w) * 8u + (lane & 7u));
-        int y = (int)((blk / blocks_w) * 8u + (lane >> 3));
-        int k = rc.spp_begin + (int)s_rel;
-        if (in_chunk != 0u && within < div && x < rc.width && y < rc.height && pixel_selected(rc, x, y)) {
-            uint32_t pixel = (uint32_t)(y * rc.width + x);
-            uint32_t pk = pixel_key(rc.seed, pixel);
-            uint32_t nk = root_node_key((uint32_t)k);
-            if (camera_sample(rc, x, y, k, pk, nk, &n.o, &n.d)) {
-                valid = true;
-                n.w = f3(1.0f, 1.0f, 1.0f);
-                n.b_pdf = 1.0f;
-                n.meta = make_meta(pixel, 0u, 1u);
-                n.nk = nk;
+    const uint32_t wg_first = blockIdx.x * RT_RAYGEN_PER_WG;
+    if (wg_first >= n_new) return; // whole workgroup idle
+    if (threadIdx.x < 2u) sm.cnt[threadIdx.x] = 0u;
+    const uint32_t per_sample = ctl->h.per_sample, n_samples = ctl->h.n_samples, chunk_samples = ctl->h.chunk_samples;
+    const uint32_t first_rem = ctl->h.first_rem, first_sample = ctl->h.first_sample;
+    const uint32_t lane = threadIdx.x & 63u;
+    Node n[RT_RAYGEN_PER_THREAD];
+    unsigned long long m_light[RT_RAYGEN_PER_THREAD], m_heavy[RT_RAYGEN_PER_THREAD];
+    uint32_t n_light = 0, n_heavy = 0; // of this wave
+#pragma unroll
+    for (int j = 0; j < RT_RAYGEN_PER_THREAD; j++) {
+        // the wave's 64 candidates are one sample of one block: everything up to the pixel is the same for its lanes
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_first + (uint32_t)j * BLOCK + (threadIdx.x & ~63u)));
+        bool valid = false;
+        if (g0 < n_new) {
+            uint32_t r = first_rem + g0; // < 2^31: the host bounds per_sample * chunk_samples and the refill level
+            uint32_t s0 = first_sample;
+            uint32_t in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
+            while (in_chunk != 0u && r >= per_sample * in_chunk) { // the batch runs over into the next chunk(s)
+                r -= per_sample * in_chunk;
+                s0 += in_chunk;
+                in_chunk = s0 < n_samples ? min(chunk_samples, n_samples - s0) : 0u;
+            }
+            const uint32_t div = 64u * max(in_chunk, 1u);
+            const uint32_t bi = min(r / div, per_sample / 64u - 1u); // in range even if the counters were inconsistent
+            const uint32_t within = r - bi * div;                      // a multiple of 64
+            const uint32_t s_rel = s0 + (within >> 6);
+            const uint32_t blk = blocks ? (uint32_t)blocks[bi] : bi;
+            const uint32_t by = blk / blocks_w, bx = blk - by * blocks_w;
+            const int x = (int)(bx * 8u + (lane & 7u));
+            const int y = (int)(by * 8u + (lane >> 3));
+            const int k = rc.spp_begin + (int)s_rel;
+            if (in_chunk != 0u && within < div && x < rc.width && y < rc.height && pixel_selected(rc, x, y)) {
+                const uint32_t pixel = (uint32_t)(y * rc.width + x);
+                const uint32_t pk = pixel_key(rc.seed, pixel);
+                const uint32_t nk = root_node_key((uint32_t)k);
+                if (camera_sample(rc, x, y, k, pk, nk, &n[j].o, &n[j].d)) {
+                    valid = true;
+                    n[j].meta = make_meta(pixel, 0u, 1u);
+                    n[j].nk = nk;
+                }
             }
         }
+        const bool heavy = valid && ray_is_heavy(sc, n[j].o, n[j].d, rc.t_min, rc.t_max);
+        m_light[j] = __ballot(valid && !heavy);
+        m_heavy[j] = __ballot(heavy);
+        n_light += (uint32_t)__popcll(m_light[j]);
+        n_heavy += (uint32_t)__popcll(m_heavy[j]);
     }
-    const bool heavy = valid && ray_is_heavy(sc, n.o, n.d, rc.t_min, rc.t_max);
+    __syncthreads(); // sm.cnt is zero
+    uint32_t wave_base = 0;
+    if (lane < 2u) {
+        const uint32_t c = lane == 0u ? n_light : n_heavy;
+        if (c) wave_base = atomicAdd(&sm.cnt[lane], c);
+    }
+    __syncthreads();
     const uint32_t seg_l = blockIdx.x % RT_NSEG_HALF, seg_h = RT_NSEG_HALF + seg_l;
-    const bool flag[6] = {valid && !heavy, false, heavy, false, false, false};
-    uint32_t *const counter[4] = {&ctl->seg_in[seg_l].v, &ctl->seg_in[seg_h].v, &ctl->seg_in[seg_l].v, &ctl->seg_in[seg_h].v};
-    uint32_t slot[6];
-    block_append(sm, flag, counter, slot);
-    if (valid) {
-        const uint32_t sl = heavy ? slot[2] : slot[0];
-        if (sl < seg_capacity) store_node(in, (heavy ? seg_h : seg_l) * seg_capacity + sl, n);
-        else ctl->h.overflow = 1;
+    if (threadIdx.x < 2u) {
+        const uint32_t c = sm.cnt[threadIdx.x];
+        sm.base[threadIdx.x] = c ? atomicAdd(&ctl->seg_in[threadIdx.x == 0u ? seg_l : seg_h].v, c) : 0u;
+    }
+    __syncthreads();
+    uint32_t at_light = sm.base[0] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 0);
+    uint32_t at_heavy = sm.base[1] + (uint32_t)__builtin_amdgcn_readlane((int)wave_base, 1);
+    auto below = [&](unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+#pragma unroll
+    for (int j = 0; j < RT_RAYGEN_PER_THREAD; j++) {
+        const bool l = (m_light[j] >> lane) & 1ull, h = (m_heavy[j] >> lane) & 1ull;
+        if (l || h) {
+            const uint32_t sl = h ? at_heavy + below(m_heavy[j]) : at_light + below(m_light[j]);
+            n[j].w = f3(1.0f, 1.0f, 1.0f);
+            n[j].b_pdf = 1.0f;
+            if (sl < seg_capacity) store_node(in, (h ? seg_h : seg_l) * seg_capacity + sl, n[j]);
+            else ctl->h.overflow = 1;
+        }
+        at_light += (uint32_t)__popcll(m_light[j]);
+        at_heavy += (uint32_t)__popcll(m_heavy[j]);
     }
 }
 
@@ -1126,6 +1130,12 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float *accum_rgb, long 
     rgb8[i] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
 }
 
+// dst += src (logical shards of one frame rendered on the same GPU)
+__global__ __launch_bounds__(BLOCK) void k_accum_add(float *dst, const float *src, long long n) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------------------
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
 // dynamic LDS of the traversal kernels: the top of the tree (when cached) + one queue area per wave
@@ -1141,7 +1151,7 @@ void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, di
 void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                    uint32_t n_threads) {
     if (!n_threads) return;
-    hipLaunchKernelGGL(k_raygen, dim3(nblocks(n_threads)), dim3(BLOCK), 0, cfg.stream, sc, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
+    hipLaunchKernelGGL(k_raygen, dim3((n_threads + RT_RAYGEN_PER_WG - 1) / RT_RAYGEN_PER_WG), dim3(BLOCK), 0, cfg.stream, sc, rc, ctl, in, blocks, blocks_w, cfg.seg_capacity);
 }
 
 static inline uint32_t class_grid(uint32_t light_threads, uint32_t heavy_threads, uint32_t *heavy_blocks, uint32_t heavy_span = 64) {
@@ -1239,6 +1249,10 @@ void launch_planes_to_rgb(const LaunchCfg &cfg, const RenderConst &rc, const flo
 
 void launch_tri_normals(hipStream_t stream, const float4 *tris, int n, float4 *out) {
     if (n > 0) hipLaunchKernelGGL(k_tri_normals, dim3(nblocks((uint32_t)n)), dim3(BLOCK), 0, stream, tris, n, out);
+}
+
+void launch_accum_add(hipStream_t stream, float *dst, const float *src, int64_t n) {
+    if (n > 0) hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, dst, src, (long long)n);
 }
 
 void launch_resolve(hipStream_t stream, const float *accum_rgb, int64_t n_pixels, int32_t spp, uint8_t *rgb8) {

@@ -178,3 +178,66 @@ def test_bench_launches_the_ranks_it_is_asked_for():
     else:
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("mode", ["tile", "spp"])
+def test_reduce_accum_through_the_c_abi(rt, monkeypatch, mode):
+    """rt_accum_create / rt_reduce_accum / rt_accum_download: the multi-GPU form of the pixel loop (src/bin/main.rs:28-52)
+    without Python in the data path.  On one GPU: two contexts (logical shards) render their share into buffers of their
+    own, the buffers that share the device are added by a kernel and the device's sum goes through a one-rank RCCL
+    communicator (RT_REDUCE_RCCL_ALWAYS=1).  The reduction itself is exact (one float addition per element); against the
+    unsharded render the sums agree to the order of the atomic adds, as for any two renders of the same samples."""
+    monkeypatch.setenv("RT_REDUCE_RCCL_ALWAYS", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    W, H, S = 256, 144, 6
+    hs = rt.HostScene("utah", W / H)
+    ctxs = [rt.Context(0), rt.Context(0)]
+    scenes = [rt.DeviceScene(c, hs.desc) for c in ctxs]
+    whole_buf = rt.DeviceAccum(ctxs[0], W, H)
+    st = scenes[0].render_device(hs.camera, rt.default_params(W, H, S), whole_buf.ptr)
+    whole = whole_buf.download()
+    accs = [rt.DeviceAccum(c, W, H) for c in ctxs]
+    cams = 0
+    for r in (0, 1):
+        p = rt.plan_shards(mode, r, 2, S, tile_size=32).apply(rt.default_params(W, H, S))
+        cams += scenes[r].render_device(hs.camera, p, accs[r].ptr).camera_samples
+    part0, part1 = accs[0].download(), accs[1].download()
+    rt.reduce_accum_devices(accs, root=0)
+    total = accs[0].download()
+    assert cams == st.camera_samples == W * H * S
+    assert np.array_equal(accs[1].download(), part1)  # the other buffers are left as they are
+    assert np.array_equal(total, part0 + part1)
+    if mode == "tile":  # disjoint pixels: every element of the sum is one shard's value
+        assert not ((part0 != 0) & (part1 != 0)).any()
+    err = (np.abs(total - whole) / np.maximum(np.abs(whole), 1e-3)).max()
+    assert err <= 1e-5, err
+    # a second reduction reuses the communicator; the root may be any index
+    rt.reduce_accum_devices([accs[1], whole_buf], root=1)
+    np.testing.assert_allclose(whole_buf.download(), whole + part1, rtol=1e-6, atol=1e-6)
+    with pytest.raises(rt.RtError):
+        rt.reduce_accum_devices([accs[0], accs[0]])
+    for a in accs + [whole_buf]:
+        a.close()
+    for s in scenes:
+        s.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_rtcli_refuses_more_gpus_than_there_are(tmp_path):
+    """rtcli --gpus N renders on devices 0..N-1 of one process (one thread and one context each, rt_reduce_accum at the
+    end); asking for more devices than the box has must end with exit code 2 before anything is written."""
+    import torch
+
+    n = torch.cuda.device_count()
+    out = tmp_path / "multi.ppm"
+    r = run_cli(4, "--scene", "head", "--width", 32, "--height", 32, "--spp", 2, "--out", out, "--gpus", n + 1)
+    assert r.returncode == 2 and f"--gpus {n + 1}" in r.stderr and not os.path.exists(out)
+    assert run_cli(4, "--gpus", 2, "--resume", tmp_path / "s.bin").returncode == 2  # one-GPU options
+    assert run_cli(4, "--shard", "rows").returncode == 2
+    if n >= 2:  # a multi-GPU box: both ways of splitting the frame give the single-GPU image
+        one = tmp_path / "one.ppm"
+        assert run_cli(4, "--scene", "head", "--width", 64, "--height", 64, "--spp", 4, "--out", one).returncode == 0
+        for shard in ("spp", "tile"):
+            assert run_cli(4, "--scene", "head", "--width", 64, "--height", 64, "--spp", 4, "--out", out, "--gpus", 2, "--shard", shard).returncode == 0
+            assert np.abs(read_ppm(out) - read_ppm(one)).max() <= 1

@@ -210,8 +210,9 @@ int32_t rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params
                   int32_t accum_is_device, rt_stats *stats);
 
 /*
- * No counterpart in the reference.  rt_render for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and results as rt_render with
+ * No counterpart in the reference.  rt_render for callers that cannot allocate device memory: while another stream of
+ * the process is capturing a graph, tight serving loops, harnesses that forbid hipMalloc (the call itself synchronises
+ * its streams and reads loop counters back, so it cannot be captured).  Same arguments and results as rt_render with
  * accum_is_device != 0 (accum_rgb_dev must be a device pointer), but the path queues, hit records, shadow queues,
  * colour planes and loop counters live in a fixed array in device memory (about 139 MB per GPU, held from library
  * load until the process ends) instead of the context's pool, and the call creates no events: it calls no hipMalloc,

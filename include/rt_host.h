@@ -61,10 +61,16 @@ int32_t rth_upscale_nearest(int32_t width, int32_t height, int32_t rate, const i
  * Resumable accumulation.  The reference streams finished rows into its PPM (src/bin/main.rs:51), so a killed run
  * leaves a truncated image; here a render is a sum buffer plus the number of samples already added to it
  * (rt_render adds samples [spp_begin, spp_end) and never clears), which can be written out and picked up again.
- * File: 32-byte header { char magic[8] = "RTACCUM1"; int32 width, height, spp, spp_done; uint32 seed, reserved }
+ * File: 32-byte header { char magic[8] = "RTACCUM1"; int32 width, height, spp, spp_done; uint32 seed, tag }
  * then width*height*3 little-endian floats.  rth_accum_load checks width, height, spp and seed against the values
  * passed in (RT_ERR_INVALID on mismatch or a short file) and returns the samples done through *spp_done.
+ * The _tagged forms also record and check a 32-bit tag of everything else the sums depend on — rth_render_tag hashes a
+ * description such as "scene|shader|pixel sampler|light sampler|light samples|depth" — so that samples of another
+ * render are never added to a saved state; the plain forms use tag 0.
  */
+uint32_t rth_render_tag(const char *description);
+int32_t rth_accum_save_tagged(const char *path, int32_t width, int32_t height, int32_t spp, int32_t spp_done, uint32_t seed, uint32_t tag, const float *accum_rgb);
+int32_t rth_accum_load_tagged(const char *path, int32_t width, int32_t height, int32_t spp, uint32_t seed, uint32_t tag, int32_t *spp_done, float *accum_rgb);
 int32_t rth_accum_save(const char *path, int32_t width, int32_t height, int32_t spp, int32_t spp_done, uint32_t seed, const float *accum_rgb);
 int32_t rth_accum_load(const char *path, int32_t width, int32_t height, int32_t spp, uint32_t seed, int32_t *spp_done, float *accum_rgb);
 

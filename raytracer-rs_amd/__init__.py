@@ -146,6 +146,12 @@ def host_lib() -> C.CDLL:
         lib.rth_accum_save.restype = C.c_int32
         lib.rth_accum_load.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_int32), c_float_p]
         lib.rth_accum_load.restype = C.c_int32
+        lib.rth_render_tag.argtypes = [C.c_char_p]
+        lib.rth_render_tag.restype = C.c_uint32
+        lib.rth_accum_save_tagged.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, c_float_p]
+        lib.rth_accum_save_tagged.restype = C.c_int32
+        lib.rth_accum_load_tagged.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), c_float_p]
+        lib.rth_accum_load_tagged.restype = C.c_int32
         _host = lib
     return _host
 

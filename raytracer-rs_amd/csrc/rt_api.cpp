@@ -355,12 +355,13 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
     if (e == hipSuccess && device_id < RT_MAX_DEVICES) {
-        // address of this device's copy of the fixed array (the device is current: hipSetDevice above)
+        // address of this device's copy of the fixed array (the device is current: hipSetDevice above).  A failed
+        // lookup only takes rt_render_static away (it reports the missing array itself); rt_render does not need it.
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
         if (!g_scratch_ptr[device_id]) {
             void *ptr = nullptr;
-            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
-            if (e == hipSuccess) g_scratch_ptr[device_id] = static_cast<unsigned char *>(ptr);
+            if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) == hipSuccess) g_scratch_ptr[device_id] = static_cast<unsigned char *>(ptr);
+            else (void)hipGetLastError(); // clears the sticky error
         }
         ctx->scratch_ptr = g_scratch_ptr[device_id];
     }
@@ -760,8 +761,17 @@ int32_t rt_scene_destroy(rt_scene *s) {
 // Allocates no device memory unless RT_FLAG_TIMING asks for events.
 static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params *p, const RenderPool &pool, uint32_t seg_capacity,
                               uint32_t shadow_seg_capacity, uint32_t target, float *accum_dev, rt_stats *stats_out,
-                              std::chrono::steady_clock::time_point t0) {
+                              std::chrono::steady_clock::time_point t0, bool fixed_pool) {
     rt_context *ctx = s->ctx;
+    // an error inside the loop leaves with both streams idle: the occlusion kernel on the second stream works in the pool
+    // (for rt_render_static: the array every context of the GPU shares) and the next call starts by clearing it
+    auto loop_fail = [&](int code, const std::string &msg) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamSynchronize(ctx->stream);
+        return fail(code, msg);
+    };
+    const char *overflow_msg = fixed_pool ? "path queue overflow: the fixed queues of rt_render_static are too small for this frame, use rt_render"
+                                          : "path queue overflow: raise RT_QUEUE_TARGET";
     const size_t n_pixels = (size_t)p->width * p->height;
     const RenderConst rcst = make_const(*cam, *p);
     const int n_samples = p->spp_end - p->spp_begin;
@@ -843,7 +853,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
-            if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
+            if (c.overflow) return loop_fail(RT_ERR_NOMEM, overflow_msg);
             if (dump_iter) // development aid: the population and the wall clock at every iteration
                 std::fprintf(stderr, "[rt] %8.3f ms: %u nodes carried in, %u camera rays to add, shadow rays <= %u + %u per segment\n",
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c.n_alive, c.n_new, c.max_sh_light,
@@ -889,7 +899,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
                 timer.end();
                 st.launches_extend++;
                 hipError_t le = hipGetLastError();
-                if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+                if (le != hipSuccess) return loop_fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
                 cur ^= 1;
                 scur ^= 1;
                 continue;
@@ -917,7 +927,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             st.launches_shade++;
             carry_in = carry_out; // the queue just written is the one read next
             hipError_t le = hipGetLastError();
-            if (le != hipSuccess) return fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
+            if (le != hipSuccess) return loop_fail(RT_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(le));
             cur ^= 1;
             scur ^= 1;
         }
@@ -927,7 +937,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         timer.collect();
         const CtlHead c = *ctx->ctl_host;
-        if (c.overflow) return fail(RT_ERR_NOMEM, "path queue overflow: raise RT_QUEUE_TARGET");
+        if (c.overflow) return fail(RT_ERR_NOMEM, overflow_msg);
         st.camera_samples = c.cam_samples;
         st.rays_closest = c.rays_closest;
         st.rays_shadow = c.rays_shadow;
@@ -1031,7 +1041,7 @@ int32_t rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, float *
     }
     pool.hit = ctx->hit.p; pool.planes = ctx->planes.p; pool.blocks = ctx->blocks.p; pool.ctl = ctx->ctl;
     rt_stats st;
-    rc = render_in_pool(s, cam, p, pool, seg_capacity, shadow_seg_capacity, target, accum_dev, &st, t0);
+    rc = render_in_pool(s, cam, p, pool, seg_capacity, shadow_seg_capacity, target, accum_dev, &st, t0, false);
     if (rc) return rc;
     if (!accum_is_device) {
         HIP_TRY(hipMemcpyAsync(accum_rgb, ctx->accum_tmp.p, 3 * n_pixels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1089,7 +1099,7 @@ int32_t rt_render_static(rt_scene *s, const rt_camera *cam, const rt_params *p, 
         pool.sc2[k] = sh2 + (size_t)k * RT_STATIC_CAPACITY;
     }
     rt_stats st;
-    rc = render_in_pool(s, cam, p, pool, RT_STATIC_SEG_CAPACITY, RT_STATIC_SEG_CAPACITY, target, accum_rgb_dev, &st, t0);
+    rc = render_in_pool(s, cam, p, pool, RT_STATIC_SEG_CAPACITY, RT_STATIC_SEG_CAPACITY, target, accum_rgb_dev, &st, t0, true);
     if (rc) return rc;
     st.device_bytes = RT_STATIC_SCRATCH_BYTES;
     if (stats) *stats = st;

@@ -714,18 +714,32 @@ namespace {
 struct AccumHeader {
     char magic[8];
     int32_t width, height, spp, spp_done;
-    uint32_t seed, reserved;
+    uint32_t seed, tag; // tag: what else the sums depend on (scene, shader, samplers ...), 0 = not recorded
 };
 static_assert(sizeof(AccumHeader) == 32, "accumulation file header is 32 bytes");
 } // namespace
 
+uint32_t rth_render_tag(const char *description) { // FNV-1a; never 0
+    uint32_t hsh = 2166136261u;
+    for (const char *c = description ? description : ""; *c; c++) hsh = (hsh ^ (uint32_t)(unsigned char)*c) * 16777619u;
+    return hsh ? hsh : 1u;
+}
+
 int32_t rth_accum_save(const char *path, int32_t w, int32_t h, int32_t spp, int32_t spp_done, uint32_t seed, const float *accum) {
+    return rth_accum_save_tagged(path, w, h, spp, spp_done, seed, 0u, accum);
+}
+
+int32_t rth_accum_load(const char *path, int32_t w, int32_t h, int32_t spp, uint32_t seed, int32_t *spp_done, float *accum) {
+    return rth_accum_load_tagged(path, w, h, spp, seed, 0u, spp_done, accum);
+}
+
+int32_t rth_accum_save_tagged(const char *path, int32_t w, int32_t h, int32_t spp, int32_t spp_done, uint32_t seed, uint32_t tag, const float *accum) {
     if (!path || !accum || w <= 0 || h <= 0 || spp <= 0 || spp_done < 0 || spp_done > spp) { g_host_err = "rth_accum_save: bad argument"; return RT_ERR_INVALID; }
     // written under a temporary name and renamed: a run killed while saving keeps the previous state
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) { g_host_err = std::string("cannot create ") + tmp; return RT_ERR_INVALID; }
-    AccumHeader hd{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'}, w, h, spp, spp_done, seed, 0u};
+    AccumHeader hd{{'R', 'T', 'A', 'C', 'C', 'U', 'M', '1'}, w, h, spp, spp_done, seed, tag};
     const size_t n = (size_t)w * (size_t)h * 3;
     bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1 && std::fwrite(accum, sizeof(float), n, f) == n;
     ok = (std::fclose(f) == 0) && ok;
@@ -733,7 +747,7 @@ int32_t rth_accum_save(const char *path, int32_t w, int32_t h, int32_t spp, int3
     return RT_OK;
 }
 
-int32_t rth_accum_load(const char *path, int32_t w, int32_t h, int32_t spp, uint32_t seed, int32_t *spp_done, float *accum) {
+int32_t rth_accum_load_tagged(const char *path, int32_t w, int32_t h, int32_t spp, uint32_t seed, uint32_t tag, int32_t *spp_done, float *accum) {
     if (!path || !accum || !spp_done) { g_host_err = "rth_accum_load: bad argument"; return RT_ERR_INVALID; }
     FILE *f = std::fopen(path, "rb");
     if (!f) { g_host_err = std::string("cannot open ") + path; return RT_ERR_INVALID; }
@@ -742,6 +756,7 @@ int32_t rth_accum_load(const char *path, int32_t w, int32_t h, int32_t spp, uint
     int32_t rc = RT_OK;
     if (std::fread(&hd, sizeof(hd), 1, f) != 1 || std::memcmp(hd.magic, "RTACCUM1", 8) != 0) { g_host_err = std::string(path) + ": not an accumulation file"; rc = RT_ERR_INVALID; }
     else if (hd.width != w || hd.height != h || hd.spp != spp || hd.seed != seed) { g_host_err = std::string(path) + ": saved for another frame size, sample count or seed"; rc = RT_ERR_INVALID; }
+    else if (hd.tag != tag) { g_host_err = std::string(path) + ": saved by another render (scene, shader, samplers, light samples or depth differ)"; rc = RT_ERR_INVALID; }
     else if (hd.spp_done < 0 || hd.spp_done > hd.spp) { g_host_err = std::string(path) + ": bad sample count"; rc = RT_ERR_INVALID; }
     else if (std::fread(accum, sizeof(float), n, f) != n) { g_host_err = std::string(path) + ": truncated"; rc = RT_ERR_INVALID; }
     else *spp_done = hd.spp_done;

@@ -87,3 +87,18 @@ def test_rust_sys_declarations_follow_the_header(rt):
                 assert rtype == "[%s; %d]" % (rust_type[ctype._type_], ctype._length_), (name, fname)
             else:
                 assert rtype.startswith("*const"), (name, fname)
+
+
+def test_integration_md_carries_the_crate_text():
+    """INTEGRATION.md section 2 must be the -sys crate itself (tools/gen_integration.py copies it in), token for token:
+    a binding copied from the document declares the same structs and functions as the one the header is checked against."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "raytracer-mi355x-sys", "src", "lib.rs")).read()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index("<!-- BEGIN lib.rs -->"):md.index("<!-- END lib.rs -->")]
+    block = block[block.index("```rust") + len("```rust"):block.rindex("```")]
+    tok = lambda t: re.findall(r"[A-Za-z_][A-Za-z0-9_]*|\d+|[^\sA-Za-z0-9_]", re.sub(r"//[^\n]*", "", t))
+    crate = tok(src[src.index("#![allow"):])
+    assert tok(block) == crate and len(crate) > 500
+    # and every function of the header is named in the document
+    for fn in declared_functions("rt_api.h"):
+        assert fn in md, fn

@@ -74,6 +74,11 @@ def test_rtcli_resumes_a_stopped_render(tmp_path):
     assert np.abs(ia - ib).max() <= 1 and (ia != ib).mean() < 0.01
     r = run_cli(*common, "--out", b, "--resume", state, "--seed", 5)  # a state file of another render is refused
     assert r.returncode == 1 and "another frame size, sample count or seed" in r.stderr
+    for other in (("--shader", "path"), ("--pixel-sampler", 2), ("--scene", "light_test")):  # ... and so is one of another scene, shader or sampler
+        r = run_cli(*common, "--out", b, "--resume", state, *other)
+        assert r.returncode == 1 and "saved by another render" in r.stderr, (other, r.stderr)
+    assert run_cli(2, *common[1:], "--out", b, "--resume", state).returncode == 1  # another light sampler (argv[1])
+    assert run_cli(*common, "--out", b, "--upscale", 100000).returncode == 2       # refused before anything is allocated
 
 
 def test_rtcli_png_and_enlarged_output(tmp_path):

@@ -155,6 +155,19 @@ def test_accumulation_files_round_trip_and_refuse_a_different_render(rt, tmp_pat
         rt.load_accum(str(tmp_path / "missing"), 7, 5, 64, seed=9)
     with pytest.raises(rt.RtError):
         rt.save_accum(path, a, spp=64, spp_done=65, seed=9)
+    # tagged states: the tag stands for everything else the sums depend on and must match on load
+    lib = rt.host_lib()
+    t1, t2 = lib.rth_render_tag(b"head|mis|4|4|9|40"), lib.rth_render_tag(b"head|path|4|4|9|40")
+    assert t1 != t2 and t1 != 0 and lib.rth_render_tag(b"") != 0
+    import ctypes as C
+    fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.rth_accum_save_tagged(path.encode(), 7, 5, 64, 24, 9, t1, fp(a)) == 0
+    back, done = np.empty_like(a), C.c_int32()
+    assert lib.rth_accum_load_tagged(path.encode(), 7, 5, 64, 9, t1, C.byref(done), fp(back)) == 0 and done.value == 24 and np.array_equal(back, a)
+    assert lib.rth_accum_load_tagged(path.encode(), 7, 5, 64, 9, t2, C.byref(done), fp(back)) == rt.RT_ERR_INVALID
+    assert b"another render" in lib.rth_last_error()
+    with pytest.raises(rt.RtError):  # the plain form is tag 0
+        rt.load_accum(path, 7, 5, 64, seed=9)
 
 
 def test_png_file_is_read_back_by_an_independent_decoder(rt, tmp_path):

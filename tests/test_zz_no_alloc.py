@@ -24,11 +24,21 @@ def close(a, b):
 
 
 def both(rt, torch, ds, cam, p):
+    """The same frame through rt_render_static and rt_render.  The static call is made twice: the first may still meet
+    one-off costs of the process (code objects loaded at a kernel's first launch); around the second the free device
+    memory (hipMemGetInfo, through torch) must not move by a byte — a hipMalloc anywhere on the path, a grown pool or a
+    new event would show up here even though the image stays the same."""
     dev = torch.device("cuda", 0)
     a = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device=dev)
     b = torch.zeros_like(a)
+    warm = torch.zeros_like(a)
     torch.cuda.synchronize()
+    ds.render_static(cam, p, warm.data_ptr())
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
     st_static = ds.render_static(cam, p, a.data_ptr())
+    free_after = torch.cuda.mem_get_info(dev)[0]
+    assert free_after == free_before, f"rt_render_static changed the free device memory by {free_before - free_after} bytes"
     st_pool = ds.render_device(cam, p, b.data_ptr())
     return a.cpu().numpy(), st_static, b.cpu().numpy(), st_pool
 

@@ -163,10 +163,13 @@ int main(int argc, char **argv) {
     if (batch <= 0) batch = spp < 16 ? spp : (spp + 15) / 16;
     unsigned long long rays = 0;
     int done = 0;
+    // a saved state belongs to one render: same scene, shader, samplers, light samples and depth (frame, samples, seed are in the header)
+    const uint32_t tag = rth_render_tag((scene + "|" + shader + "|" + std::to_string(pixel_sampler) + "|" + std::to_string(light_sampler) + "|" +
+                                         std::to_string(p.light_samples) + "|" + std::to_string(p.max_depth)).c_str());
     if (!resume.empty()) {
         if (FILE *probe = std::fopen(resume.c_str(), "rb")) {
             std::fclose(probe);
-            if (rth_accum_load(resume.c_str(), width, height, spp, seed, &done, accum.data()) != RT_OK) {
+            if (rth_accum_load_tagged(resume.c_str(), width, height, spp, seed, tag, &done, accum.data()) != RT_OK) {
                 std::fprintf(stderr, "Error: %s\n", rth_last_error());
                 return 1;
             }
@@ -185,7 +188,7 @@ int main(int argc, char **argv) {
         rays += st.rays_closest + st.rays_shadow;
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - now).count();
         std::printf("Now rendering: %g%%, %lld seconds elapsed\n", (double)(p.spp_end * 100) / (double)spp, (long long)secs);
-        if (!resume.empty() && rth_accum_save(resume.c_str(), width, height, spp, p.spp_end, seed, accum.data()) != RT_OK) {
+        if (!resume.empty() && rth_accum_save_tagged(resume.c_str(), width, height, spp, p.spp_end, seed, tag, accum.data()) != RT_OK) {
             std::fprintf(stderr, "Error: %s\n", rth_last_error());
             return 1;
         }

@@ -25,7 +25,8 @@ const char *rth_last_error(void);
  * `light_sampler` is the SamplerKind given to the scene constructors (src/bin/main.rs:15-22);
  * `asset_dir` holds cube.obj, pyramid.obj, utah.obj, miku.obj.
  * Names: "head" (Scene::cornell_box as it stands at HEAD), "blue_noise_test", "light_test", "mis_test"
- * (src/scene.rs:356,403,554), and the benchmark scenes "cornell", "whitted", "utah", "miku", "composite".
+ * (src/scene.rs:356,403,554), the benchmark scenes "cornell", "whitted", "utah", "miku", "composite", and "cornell_1light" / "cornell_2light": the box
+ * with the chess board back wall and the disk lights of src/scene.rs:136-142,327-344 (the renders under output/sampling/cornell).
  */
 int32_t rth_scene_create(const char *name, float aspect, int32_t light_sampler, const char *asset_dir, rth_scene **out);
 void rth_scene_destroy(rth_scene *s);

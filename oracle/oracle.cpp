@@ -1079,6 +1079,16 @@ V3 path_trace_shader(const Ctx &cx, const Ray &r, int depth, uint32_t nk) {
     return BLACK;
 }
 
+// Oracle-only switch for the two renders the reference's authors made with ONE term of Microfacet::do_material: the
+// returns left as comments at material.rs:449-450 (`// direct`, `// brdf`).  Only the Microfacet estimator was switched:
+// on the Diffuse walls of output/sampling/mis/test/{brdf,direct}.jpg the block means equal those of mis.jpg to 1 %,
+// which two different Monte-Carlo estimators would not give; do_material_default (material.rs:454-484) stayed whole.
+//   0  the code at HEAD: brdf + direct
+//   1  Microfacet::do_material returns `brdf`   (its specular + diffuse children)   -> .../mis/test/brdf.jpg
+//   2  Microfacet::do_material returns `direct` (its next-event term)               -> .../mis/test/direct.jpg
+// The product has no such switch; set through orc_set_estimator_terms by the tests that compare with those renders.
+int g_estimator_terms = 0;
+
 // the NEE term shared by do_material_default and Microfacet::do_material (material.rs:441-447, 473-480)
 V3 direct_term(const Ctx &cx, const rt_material &m, const Ray &r, const Hit &rec, uint32_t nk) {
     LSample ls;
@@ -1151,6 +1161,8 @@ V3 do_material_microfacet(const Ctx &cx, const rt_material &m, const Ray &r, con
     }
     V3 brdf = mul_v(kd, diffuse) + specular;
     V3 direct = direct_term(cx, m, r, rec, nk);
+    if (g_estimator_terms == 1) return brdf;   // material.rs:450
+    if (g_estimator_terms == 2) return direct; // material.rs:449
     return brdf + direct;
 }
 
@@ -1305,6 +1317,9 @@ int32_t orc_scene_create(const rt_scene_desc *d, int32_t accel_mode, orc_scene *
 }
 
 void orc_scene_destroy(orc_scene *s) { delete s; }
+
+// see g_estimator_terms; not thread-safe against a running orc_render
+void orc_set_estimator_terms(int32_t mode) { g_estimator_terms = mode == 1 || mode == 2 ? mode : 0; }
 
 // main.rs:28-44 (accumulation only; the division by NS and the gamma are orc_resolve)
 int32_t orc_render(orc_scene *s, const rt_camera *cam, const rt_params *pr, float *accum_rgb, rt_stats *stats, int32_t n_threads) {

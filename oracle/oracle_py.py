@@ -30,6 +30,8 @@ def lib() -> C.CDLL:
         L.orc_last_error.restype = C.c_char_p
         L.orc_scene_create.argtypes = [C.POINTER(rt.SceneDesc), C.c_int32, C.POINTER(C.c_void_p)]
         L.orc_scene_create.restype = C.c_int32
+        L.orc_set_estimator_terms.argtypes = [C.c_int32]
+        L.orc_set_estimator_terms.restype = None
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_destroy.restype = None
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(rt.Camera), C.POINTER(rt.Params), c_float_p, C.POINTER(rt.Stats), C.c_int32]

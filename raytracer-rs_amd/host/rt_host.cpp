@@ -507,6 +507,39 @@ Scene Scene::bench_whitted(SamplerKind k, float aspect, const std::string &asset
     return s;
 }
 
+// The scene of output/sampling/cornell/{1light,2light}/*_16spp.jpg (and of output/path1.jpg, sampling/mis/{brdf,mis}_*spp.jpg):
+// the box with the chess board of scene.rs:136-142 as its back wall, the objects of scene.rs:173-218 (comments) in their
+// Whitted-compatible materials, and the disk lights of scene.rs:327-344: one warm light in the middle of the ceiling,
+// or the magenta and the cyan one.  The two figure meshes of those renders are not in the repository and are left out.
+Scene Scene::cornell_sampling(SamplerKind k, float aspect, const std::string &assets, int n_lights) {
+    Scene s;
+    s.cam = cornell_camera(aspect);
+    s.world.objects.push(placed_utah(assets, std::make_shared<Diffuse>(RGBSpectrum(1.0f, 1.0f, 1.0f))));
+    s.world.objects.push(placed_pyramid(assets, std::make_shared<Metal>(RGBSpectrum(1.0f, 1.0f, 1.0f))));
+    Pt3 v1(-1, -1, -1), v2(1, -1, -1), v3(1, -1, -3), v4(-1, -1, -3);
+    Pt3 v5(-1, 1, -1), v6(1, 1, -1), v7(1, 1, -3), v8(-1, 1, -3);
+    auto floor = make_square(v1, v2, v3, v4, RGBSpectrum(0.9f, 0.9f, 0.9f));
+    auto ceiling = make_square(v5, v8, v7, v6, RGBSpectrum(0.9f, 0.9f, 0.9f));
+    s.world.objects.push(floor.first); s.world.objects.push(floor.second);
+    s.world.objects.push(ceiling.first); s.world.objects.push(ceiling.second);
+    FastMesh board(make_chess_board(v4, v3, v7, v8, 12)); // scene.rs:136-142
+    board.rotate(0.01f, 0.0f, 0.0f);
+    s.world.objects.push(std::move(board));
+    auto left = make_square(v1, v4, v8, v5, RGBSpectrum(0.7f, 0.0f, 0.0f));
+    auto right = make_square(v3, v2, v6, v7, RGBSpectrum(0.0f, 0.4f, 0.0f));
+    s.world.objects.push(left.first); s.world.objects.push(left.second);
+    s.world.objects.push(right.first); s.world.objects.push(right.second);
+    s.world.objects.push(Cylinder(0.1f, -1.95f, -1.0f, -0.5f, 0.4f, std::make_shared<Metal>(RGBSpectrum(0.9f, 0.7f, 0.4f))));
+    s.world.objects.push(Sphere(Vec3(-0.34f, 0.38f, -2.0f), 0.25f, std::make_shared<Metal>(RGBSpectrum(0.4f, 0.7f, 0.9f))));
+    if (n_lights == 1) {
+        s.world.lights.push(DiskLight(Pt3(0.0f, 1.0f, -2.0f), 0.4f, RGBSpectrum(0.9f, 0.64f, 0.48f) * 6.0f, k));  // scene.rs:327-332
+    } else {
+        s.world.lights.push(DiskLight(Pt3(-0.45f, 1.0f, -2.25f), 0.4f, RGBSpectrum(0.9f, 0.0f, 0.48f) * 6.0f, k)); // scene.rs:333-338
+        s.world.lights.push(DiskLight(Pt3(0.45f, 1.0f, -1.75f), 0.4f, RGBSpectrum(0.0f, 0.63f, 0.48f) * 6.0f, k)); // scene.rs:339-344
+    }
+    return s;
+}
+
 // Box + ceiling light + Utah teapot with the Microfacet of scene.rs:71-76.
 Scene Scene::bench_utah(SamplerKind, float aspect, const std::string &assets) {
     Scene s;
@@ -569,6 +602,8 @@ int32_t rth_scene_create(const char *name, float aspect, int32_t light_sampler, 
         else if (n == "mis_test") s = rt::Scene::mis_test(k, aspect);
         else if (n == "cornell") s = rt::Scene::bench_cornell(k, aspect, assets);
         else if (n == "whitted") s = rt::Scene::bench_whitted(k, aspect, assets);
+        else if (n == "cornell_1light") s = rt::Scene::cornell_sampling(k, aspect, assets, 1);
+        else if (n == "cornell_2light") s = rt::Scene::cornell_sampling(k, aspect, assets, 2);
         else if (n == "utah") s = rt::Scene::bench_utah(k, aspect, assets);
         else if (n == "miku") s = rt::Scene::bench_miku(k, aspect, assets);
         else if (n == "composite") s = rt::Scene::bench_composite(k, aspect, assets);

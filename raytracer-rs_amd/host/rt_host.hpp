@@ -202,6 +202,7 @@ struct Scene {
     // benchmark scenes assembled from the reference's walls, light, meshes and (commented) materials
     static Scene bench_cornell(SamplerKind k, float aspect, const std::string &assets);
     static Scene bench_whitted(SamplerKind k, float aspect, const std::string &assets);
+    static Scene cornell_sampling(SamplerKind k, float aspect, const std::string &assets, int n_lights);
     static Scene bench_utah(SamplerKind k, float aspect, const std::string &assets);
     static Scene bench_miku(SamplerKind k, float aspect, const std::string &assets);
     static Scene bench_composite(SamplerKind k, float aspect, const std::string &assets);

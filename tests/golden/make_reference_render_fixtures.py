@@ -11,6 +11,17 @@ source is a JPEG the reference's authors rendered with the scene constructor nam
   output/cornell.jpg                            <- the Cornell scene kept as comments in Scene::cornell_box (src/scene.rs:65-118,
         173-218); its two figure meshes are not in the repository, so only regions away from them are kept
 
+  output/sampling/mis/test/brdf.jpg, direct.jpg  <- Scene::mis_test with Microfacet::do_material returning one of its two
+        terms (the returns left as comments at src/material.rs:449-450); Diffuse surfaces render as in mis.jpg
+  output/final3.jpg, final40spp.jpg             <- the composite kept as comments in Scene::cornell_box (src/scene.rs:65-118,
+        173-218): Microfacet pyramid / cylinder / sphere / figure, Diffuse teapot, glass figure, polygon light; regions
+        away from the two figure meshes (absent from the repository)
+  output/sampling/mis/mis_40spp.jpg             <- the same box with the chess board back wall and the one disk light of
+        src/scene.rs:327-332 under path_trace_shader_mis
+  output/sampling/cornell/1light/*_16spp.jpg    <- that scene under whitted_trace_shader, light samplers white / uniform /
+        jittered / blue (DiskLight::visible, src/light.rs:150-181).  Stored in LINEAR units ((v / 255.99)^2 averaged):
+        the test compares ratios, see tests/test_oracle_reference_renders.py
+
 Stored: for the deterministic chessboard renders the 200x200 image itself (centre 4x4 of every 8x8 block, averaged);
 for everything else block means on a coarse grid, or means of hand-picked regions.
 """
@@ -83,6 +94,52 @@ for name, (x0, y0, x1, y1) in CORNELL_REGIONS.items():
     sub = img[int(y0 * h):max(int(y0 * h) + 1, int(y1 * h)), int(x0 * w):max(int(x0 * w) + 1, int(x1 * w))]
     meta["cornell_regions"][name] = {"box": [x0, y0, x1, y1], "mean_rgb": [round(float(v), 2) for v in sub.reshape(-1, 3).mean(0)]}
 meta["sources"]["cornell_regions"] = "cornell.jpg"
+
+# ---- one term of the Microfacet estimator at a time
+for key, rel in {"mis_test_brdf": "sampling/mis/test/brdf.jpg", "mis_test_direct": "sampling/mis/test/direct.jpg"}.items():
+    img = load(rel)
+    assert img.shape == (800, 800, 3)
+    arrays[key + "_grid40"] = u8(grid(img, 40))
+    meta["sources"][key + "_grid40"] = rel
+
+
+def region_means(img, regions, linear=False):
+    h, w, _ = img.shape
+    out = {}
+    for name, (x0, y0, x1, y1) in regions.items():
+        sub = img[int(y0 * h):max(int(y0 * h) + 1, int(y1 * h)), int(x0 * w):max(int(x0 * w) + 1, int(x1 * w))].reshape(-1, 3)
+        if linear:
+            sub = (sub / 255.99) ** 2
+        out[name] = {"box": [x0, y0, x1, y1], "mean_rgb": [round(float(v), 5 if linear else 2) for v in sub.mean(0)]}
+    return out
+
+
+# ---- the composite (final3.jpg: converged; final40spp.jpg: 40 samples): regions the two absent figure meshes neither
+# cover nor light (the glass figure on the left throws caustics on the lower left wall and the cylinder: left out)
+COMPOSITE_REGIONS = {
+    "left_wall": (0.03, 0.30, 0.12, 0.60), "right_wall": (0.88, 0.30, 0.97, 0.60), "back_upper": (0.45, 0.22, 0.60, 0.30),
+    "back_mid_right": (0.70, 0.30, 0.78, 0.34), "ceiling_left": (0.15, 0.04, 0.35, 0.10), "ceiling_right": (0.65, 0.04, 0.85, 0.10),
+    "floor_front": (0.40, 0.94, 0.60, 0.99), "light": (0.44, 0.11, 0.56, 0.135), "teapot_body": (0.49, 0.625, 0.58, 0.655),
+    "pyramid_green_face": (0.62, 0.42, 0.66, 0.47), "pyramid_left_face": (0.585, 0.47, 0.60, 0.49), "sphere_dark_side": (0.33, 0.30, 0.37, 0.36),
+    "right_wall_low": (0.94, 0.65, 0.98, 0.85),
+}
+for key, rel in {"composite_regions": "final3.jpg", "composite_40spp_regions": "final40spp.jpg"}.items():
+    meta[key] = region_means(load(rel), COMPOSITE_REGIONS)
+    meta["sources"][key] = rel
+
+# ---- the box with the chess board and one disk light: MIS shader
+meta["cornell_disk_mis_regions"] = region_means(load("sampling/mis/mis_40spp.jpg"), {
+    "left_wall": (0.03, 0.30, 0.12, 0.60), "floor_front": (0.40, 0.94, 0.60, 0.99), "teapot_body": (0.49, 0.625, 0.58, 0.655),
+    "ceiling_left": (0.05, 0.04, 0.15, 0.08), "right_wall": (0.88, 0.30, 0.97, 0.60)})
+meta["sources"]["cornell_disk_mis_regions"] = "sampling/mis/mis_40spp.jpg"
+
+# ---- ... and the Whitted shader, four light samplers; grey surfaces no figure shadows, in linear units
+WHITTED_REGIONS = {"floor_front": (0.40, 0.93, 0.60, 0.98), "floor_mid_left": (0.34, 0.80, 0.38, 0.84), "back_row_11": (0.21, 0.706, 0.25, 0.744),
+                   "teapot_body": (0.49, 0.625, 0.58, 0.655), "left_wall_mid": (0.03, 0.45, 0.10, 0.60), "right_wall_mid": (0.90, 0.50, 0.97, 0.62)}
+meta["cornell_disk_whitted_linear"] = {}
+for sampler, fname in {"white": "white_16spp.jpg", "uniform": "uniform_16spp.jpg", "jittered": "jigger_16spp.jpg", "blue": "blue_16spp.jpg"}.items():
+    meta["cornell_disk_whitted_linear"][sampler] = region_means(load("sampling/cornell/1light/" + fname), WHITTED_REGIONS, linear=True)
+meta["sources"]["cornell_disk_whitted_linear"] = "sampling/cornell/1light/*_16spp.jpg"
 
 np.savez_compressed(os.path.join(HERE, "reference_renders.npz"), **arrays)
 with open(os.path.join(HERE, "reference_renders.json"), "w") as f:

@@ -745,6 +745,67 @@ def test_gpu_light_scene_matches_the_reference_render(rt, gpu_ctx, golden_dir):
     ds.close()
 
 
+def _region_mean(img, box):
+    h, w, _ = img.shape
+    x0, y0, x1, y1 = box
+    return img[int(y0 * h):max(int(y0 * h) + 1, int(y1 * h)), int(x0 * w):max(int(x0 * w) + 1, int(x1 * w))].reshape(-1, 3).astype(np.float64).mean(0)
+
+
+def test_gpu_composite_scene_matches_the_reference_renders(rt, gpu_ctx, golden_dir):
+    """output/final3.jpg and final40spp.jpg (the composite of the largest benchmark configuration: Microfacet pyramid,
+    cylinder, sphere and figure, Diffuse teapot, glass figure, PolygonLight) on the HIP path, full 800 x 800 frame:
+    walls, ceiling, floor, teapot, pyramid faces and sphere, away from the two figure meshes the repository lacks."""
+    import json
+
+    meta = json.load(open(os.path.join(golden_dir, "reference_renders.json")))
+    hs = rt.HostScene("composite", 1.0)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    spp = 256
+    acc, _ = ds.render(hs.camera, rt.default_params(800, 800, spp, seed=2))
+    u8 = rt.resolve(acc, spp)[1]
+    for key in ("composite_regions", "composite_40spp_regions"):
+        for name, r in meta[key].items():
+            got = _region_mean(u8, r["box"])
+            assert np.abs(got - np.array(r["mean_rgb"])).max() < 9.0, (key, name, got, r["mean_rgb"])
+    ds.close()
+
+
+def test_gpu_disk_light_box_matches_the_reference_renders(rt, gpu_ctx, golden_dir):
+    """The box with the chess board back wall and one disk light (src/scene.rs:136-142,327-332) on the HIP path against
+    the reference's own renders: output/sampling/mis/mis_40spp.jpg under the MIS shader (levels), and
+    output/sampling/cornell/1light/*_16spp.jpg under the Whitted shader (DiskLight::visible with each light sampler; those
+    renders are older than HEAD by one constant factor, so one ratio for every grey region and channel is what is held —
+    see tests/test_oracle_reference_renders.py)."""
+    import json
+
+    meta = json.load(open(os.path.join(golden_dir, "reference_renders.json")))
+    hs = rt.HostScene("cornell_1light", 1.0, light_sampler=rt.SAMPLER_BLUE)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    spp = 400
+    acc, _ = ds.render(hs.camera, rt.default_params(800, 800, spp, seed=2))
+    u8 = rt.resolve(acc, spp)[1]
+    regs = meta["cornell_disk_mis_regions"]
+    for name in ("left_wall", "floor_front", "teapot_body", "ceiling_left"):
+        got = _region_mean(u8, regs[name]["box"])
+        assert np.abs(got - np.array(regs[name]["mean_rgb"])).max() < 9.0, (name, got, regs[name]["mean_rgb"])
+    ds.close()
+    for sampler, kind in (("white", 1), ("uniform", 2), ("jittered", 3), ("blue", 4)):
+        hs = rt.HostScene("cornell_1light", 1.0, light_sampler=kind)
+        ds = rt.DeviceScene(gpu_ctx, hs.desc)
+        spp = 64
+        acc, _ = ds.render(hs.camera, rt.default_params(800, 800, spp, shader=rt.SHADER_WHITTED, seed=3))
+        lin = np.minimum(acc / spp, 1.0)
+        ratios = []
+        for name in ("floor_front", "floor_mid_left", "back_row_11", "teapot_body"):
+            r = meta["cornell_disk_whitted_linear"][sampler][name]
+            ratio = _region_mean(lin, r["box"]) / np.array(r["mean_rgb"])
+            assert ratio.max() / ratio.min() < 1.06, (sampler, name, ratio)
+            ratios.append(ratio.mean())
+        ratios = np.array(ratios)
+        assert 3.0 < ratios.min() and ratios.max() < 3.9 and 3.15 < np.median(ratios) < 3.55, (sampler, ratios)
+        ds.close()
+
+
 # ---- the acceleration structure built on the GPU ------------------------------------------------------------------------
 @pytest.mark.parametrize("loose_max", ["16", "0"])
 @pytest.mark.parametrize("scene,W,H", [("utah", 160, 90), ("miku", 160, 90), ("composite", 96, 54), ("blue_noise_test", 64, 64), ("head", 48, 48)])

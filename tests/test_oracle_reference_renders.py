@@ -105,3 +105,95 @@ def test_cornell_box_regions_away_from_the_missing_meshes(rt, orc, ref):
         sub = u8[int(y0 * H):max(int(y0 * H) + 1, int(y1 * H)), int(x0 * W):max(int(x0 * W) + 1, int(x1 * W))].reshape(-1, 3).astype(float)
         tol = 30.0 if name == "sphere_highlight" else 12.0  # a small bright spot next to dark pixels
         assert np.abs(sub.mean(0) - np.array(r["mean_rgb"])).max() < tol, (name, sub.mean(0), r["mean_rgb"])
+
+
+def region_mean(img, box):
+    h, w, _ = img.shape
+    x0, y0, x1, y1 = box
+    return img[int(y0 * h):max(int(y0 * h) + 1, int(y1 * h)), int(x0 * w):max(int(x0 * w) + 1, int(x1 * w))].reshape(-1, 3).astype(np.float64).mean(0)
+
+
+@pytest.mark.parametrize("mode,key,tol_mean,tol_p95", [(1, "mis_test_brdf_grid40", 5.0, 20.0), (2, "mis_test_direct_grid40", 3.5, 10.0)])
+def test_mis_scene_one_term_of_the_microfacet_estimator(rt, orc, ref, mode, key, tol_mean, tol_p95):
+    """output/sampling/mis/test/brdf.jpg and direct.jpg: Microfacet::do_material returning `brdf` (its two scattered
+    children) or `direct` (its next-event term) alone — the returns left as comments at src/material.rs:449-450 — while
+    Diffuse surfaces keep the whole estimator.  An oracle-only switch reproduces the two; each half of the estimator is
+    thereby held to a render of its own (the sum is held to mis.jpg above)."""
+    want = ref[0][key].astype(np.float64)
+    hs = rt.HostScene("mis_test", 1.0)
+    spp = 64
+    orc.lib().orc_set_estimator_terms(mode)
+    try:
+        acc, _ = orc.OracleScene(hs.desc, 0).render(hs.camera, rt.default_params(200, 200, spp, seed=5))
+    finally:
+        orc.lib().orc_set_estimator_terms(0)
+    got = block_means(orc.resolve(acc, spp)[1], 40)
+    d = np.abs(got - want).max(axis=2)
+    assert d.mean() < tol_mean and np.percentile(d, 95) < tol_p95, (d.mean(), np.percentile(d, 95))
+    # the other term, or the sum, is clearly worse against this render
+    whole = ref[0]["mis_test_grid40"].astype(np.float64)
+    assert np.abs(whole - want).max(axis=2).mean() > 1.5 * d.mean()
+
+
+def test_composite_scene_regions_away_from_the_missing_meshes(rt, orc, ref):
+    """output/final3.jpg (converged) and final40spp.jpg: the composite with Microfacet pyramid, cylinder, sphere and figure,
+    Diffuse teapot, glass figure and the ceiling PolygonLight — the benchmark's largest scene.  Walls, ceiling (lit only
+    indirectly), floor, teapot, both pyramid faces and the dark side of the sphere, away from the two figure meshes that
+    are not in the reference repository."""
+    hs = rt.HostScene("composite", 1.0)
+    W = H = 160
+    spp = 64
+    acc, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, rt.default_params(W, H, spp, seed=5))
+    u8 = orc.resolve(acc, spp)[1]
+    for key in ("composite_regions", "composite_40spp_regions"):
+        for name, r in ref[1][key].items():
+            # small regions of a 160 x 160 frame; the square root of a noisy 64-sample mean is biased low on the bright floor
+            tol = 14.0 if name in ("teapot_body", "pyramid_left_face", "pyramid_green_face") else 10.0
+            got = region_mean(u8, r["box"])
+            assert np.abs(got - np.array(r["mean_rgb"])).max() < tol, (key, name, got, r["mean_rgb"])
+
+
+def test_cornell_box_with_one_disk_light_under_the_mis_shader(rt, orc, ref):
+    """output/sampling/mis/mis_40spp.jpg: the box with the chess board back wall and the disk light of src/scene.rs:327-332
+    under path_trace_shader_mis — DiskLight::{hit, pdf, visible_d} in a closed room, the ceiling lit by bounces only.
+    The right wall is left out: its green was twice as bright in that render as (0, 0.4, 0) of src/scene.rs:135 gives
+    (measured ratio of linear values 2.07; every other surface agrees), i.e. the wall's albedo was changed afterwards."""
+    hs = rt.HostScene("cornell_1light", 1.0, light_sampler=rt.SAMPLER_BLUE)
+    W = H = 160
+    spp = 64
+    acc, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, rt.default_params(W, H, spp, seed=5))
+    u8 = orc.resolve(acc, spp)[1]
+    regs = ref[1]["cornell_disk_mis_regions"]
+    for name in ("left_wall", "floor_front", "teapot_body", "ceiling_left"):
+        got = region_mean(u8, regs[name]["box"])
+        assert np.abs(got - np.array(regs[name]["mean_rgb"])).max() < 9.0, (name, got, regs[name]["mean_rgb"])
+    g_ours, g_ref = region_mean(u8, regs["right_wall"]["box"])[1], regs["right_wall"]["mean_rgb"][1]
+    assert 1.8 < (g_ref / g_ours) ** 2 < 2.4  # the documented exception, not a tolerance
+
+
+@pytest.mark.parametrize("sampler,kind", [("white", 1), ("uniform", 2), ("jittered", 3), ("blue", 4)])
+def test_whitted_disk_light_estimate_has_the_reference_s_shape(rt, orc, ref, sampler, kind):
+    """output/sampling/cornell/1light/*_16spp.jpg: whitted_trace_shader with the disk light, i.e. DiskLight::visible
+    (src/light.rs:150-181: sampler points inside the disk, spectrum * cos / dist^2 averaged, times pi r^2) for each of the
+    four light samplers.  Those renders are older than HEAD by a constant: on every grey, unshadowed surface the HEAD
+    formula (direct * attenuation, src/shader.rs:42) is brighter than the render by one and the same ratio — 3.1 to 3.8,
+    median 3.25 for the uniform sampler and 3.42 = 1.09 pi for the random ones — in all three channels and in every region: what multiplying by
+    brdf() = albedo / pi instead of attenuation() gives, times a 9 % change of some constant (the light's "* 6.0" of
+    src/scene.rs:330 is the likeliest).  Reported, not tuned away: the test holds the oracle to ONE ratio in that band,
+    so the estimate's dependence on distance, angle, light size and sampler is the reference's; its absolute level at
+    HEAD is pinned by nothing the reference holds.  The side walls (albedos changed since, see the MIS test above) are
+    not compared."""
+    hs = rt.HostScene("cornell_1light", 1.0, light_sampler=kind)
+    W = H = 200
+    spp = 16
+    acc, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, rt.default_params(W, H, spp, shader=rt.SHADER_WHITTED, seed=3))
+    lin = np.minimum(acc / spp, 1.0)
+    ratios = []
+    for name in ("floor_front", "floor_mid_left", "back_row_11", "teapot_body"):
+        r = ref[1]["cornell_disk_whitted_linear"][sampler][name]
+        ratio = region_mean(lin, r["box"]) / np.array(r["mean_rgb"])
+        assert ratio.max() / ratio.min() < 1.06, (name, ratio)  # no colour shift
+        ratios.append(ratio.mean())
+    ratios = np.array(ratios)
+    assert 3.0 < ratios.min() and ratios.max() < 3.9 and ratios.max() / ratios.min() < 1.22, ratios
+    assert 3.15 < np.median(ratios) < 3.55, ratios  # measured medians: 3.25 (uniform grid on the disk), 3.42 (the three random samplers)

@@ -38,17 +38,29 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // NEAR > 0 (chains only): of every NEAR + 1 loads of a lane, NEAR go to the slot after the previous one (the lane's own
 // cache line again, unless it ended there) — what a depth-first node order gives a walk.  NEAR < 0: every step loads a
 // slot AND the slot after it, both in flight together.
-template <int WIDTH, bool CHAIN, bool SAME_LINE, int NEAR = 0>
+// GROUP > 1: GROUP neighbouring lanes read the GROUP consecutive 16-byte pieces of one random record of 16 * GROUP bytes
+// (aligned to its size): what a fetch of a 32- or 64-byte record shared out over a lane pair or quad looks like.
+template <int WIDTH, bool CHAIN, bool SAME_LINE, int NEAR = 0, int GROUP = 1>
 __global__ __launch_bounds__(256) void k_loads(const uint4 *table, uint32_t n_slots, uint32_t iters, uint32_t active, uint32_t *sink) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(table), (short)0, (int)(n_slots * 16u), 0x00020000);
     // which lanes take part: a fixed pseudo-random subset of the wave, the same in every wave
-    const bool on = (mix32(lane * 0x9E3779B9u + 12345u) % 64u) < active || active >= 64u;
+    const bool on = (GROUP == 4 && active == 48u) ? (lane % 4u) < 3u // (three lanes of every quad)
+                                                   : (mix32(lane * 0x9E3779B9u + 12345u) % 64u) < active || active >= 64u;
     uint32_t acc = 0;
     if (on) {
-        uint32_t s = mix32(SAME_LINE ? (gid >> 6) : gid);
-        if (CHAIN) {
+        uint32_t s = mix32(SAME_LINE ? (gid >> 6) : (GROUP > 1 ? gid / GROUP : gid));
+        if (CHAIN && GROUP > 1) {
+            uint32_t rec = __umulhi(s, n_slots / GROUP);
+            for (uint32_t i = 0; i < iters; i++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((rec * GROUP + lane % GROUP) * 16u), 0, 0);
+                uint32_t w = v.x ^ v.w;
+                for (int sh = 1; sh < GROUP; sh <<= 1) w ^= (uint32_t)__shfl_xor((int)w, sh); // the group goes on together
+                acc += w;
+                rec = __umulhi(mix32(w + i + (gid / GROUP) * 0x9E3779B9u), n_slots / GROUP); // (with the group's id: chains of different groups never merge)
+            }
+        } else if (CHAIN) {
             uint32_t slot = __umulhi(s, n_slots);
             for (uint32_t i = 0; i < iters; i++) {
                 uint32_t w;
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void k_loads(const uint4 *table, uint32_t n_sl
                 else w = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(slot * 16u), 0, 0);
                 acc += w;
                 if (NEAR > 0 && (i % (NEAR + 1)) != 0u) slot = slot + 1u < n_slots ? slot + 1u : 0u;
-                else slot = __umulhi(mix32(w + i), n_slots); // the table holds random words; with i, no lane falls into a cycle
+                else slot = __umulhi(mix32(w + i + gid * 0x9E3779B9u), n_slots); // with i and the lane's id: no cycles, and chains of different lanes never merge
             }
         } else {
             for (uint32_t i = 0; i < iters; i += 8) {
@@ -71,7 +83,8 @@ __global__ __launch_bounds__(256) void k_loads(const uint4 *table, uint32_t n_sl
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     s = s * 1664525u + 1013904223u;
-                    uint32_t slot = SAME_LINE ? (__umulhi(mix32(s), n_slots / 64u) * 64u + lane) : __umulhi(mix32(s), n_slots);
+                    uint32_t slot = SAME_LINE ? (__umulhi(mix32(s), n_slots / 64u) * 64u + lane)
+                                  : GROUP > 1 ? (__umulhi(mix32(s), n_slots / GROUP) * GROUP + lane % GROUP) : __umulhi(mix32(s), n_slots);
                     if (WIDTH == 16) { const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(slot * 16u), 0, 0); w[k] = v.x ^ v.w; }
                     else if (WIDTH == 8) { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(slot * 16u), 0, 0); w[k] = v.x ^ v.y; }
                     else w[k] = __builtin_amdgcn_raw_buffer_load_b32(r, (int)(slot * 16u), 0, 0);
@@ -84,6 +97,32 @@ __global__ __launch_bounds__(256) void k_loads(const uint4 *table, uint32_t n_sl
     if (acc == 0x12345u) sink[gid & 1023u] = acc; // keeps the loads alive
 }
 
+// One lane fetches a whole record by itself: PIECES loads of 16 bytes at consecutive addresses, records STRIDE bytes apart
+// (48: packed triangle records, which straddle cache lines; 32 / 64: aligned records).  Independent records, 2 per round.
+template <int PIECES, int STRIDE>
+__global__ __launch_bounds__(256) void k_records(const uint4 *table, uint32_t n_slots, uint32_t iters, uint32_t *sink) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(table), (short)0, (int)(n_slots * 16u), 0x00020000);
+    const uint32_t n_rec = (n_slots * 16u) / STRIDE - 1u;
+    uint32_t s = mix32(gid), acc = 0;
+    for (uint32_t i = 0; i < iters; i += 2) {
+        uint32_t w[2 * PIECES];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            s = s * 1664525u + 1013904223u;
+            const uint32_t off = __umulhi(mix32(s), n_rec) * STRIDE;
+#pragma unroll
+            for (int p = 0; p < PIECES; p++) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u * p), 0, 0);
+                w[k * PIECES + p] = v.x ^ v.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * PIECES; k++) acc += w[k];
+    }
+    if (acc == 0x12345u) sink[gid & 1023u] = acc;
+}
+
 struct Result {
     std::string name;
     int width, active, waves_per_simd;
@@ -91,7 +130,7 @@ struct Result {
     double ms, glane, gwave;
 };
 
-template <int WIDTH, bool CHAIN, bool SAME_LINE, int NEAR = 0>
+template <int WIDTH, bool CHAIN, bool SAME_LINE, int NEAR = 0, int GROUP = 1>
 static Result run(const char *name, const uint4 *table, uint32_t n_slots, uint32_t active, int waves_per_simd, uint32_t *sink, int n_cu) {
     const uint32_t blocks = (uint32_t)(n_cu * waves_per_simd); // 4 waves per block, 4 SIMDs per CU
     uint32_t iters = CHAIN ? 2048u : 8192u;
@@ -101,7 +140,7 @@ static Result run(const char *name, const uint4 *table, uint32_t n_slots, uint32
     float ms = 0.0f;
     for (int rep = 0; rep < 5; rep++) { // the first launch warms the caches; the best of the others counts
         CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k_loads<WIDTH, CHAIN, SAME_LINE, NEAR>), dim3(blocks), dim3(256), 0, 0, table, n_slots, iters, active, sink);
+        hipLaunchKernelGGL((k_loads<WIDTH, CHAIN, SAME_LINE, NEAR, GROUP>), dim3(blocks), dim3(256), 0, 0, table, n_slots, iters, active, sink);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         float t;
@@ -116,6 +155,31 @@ static Result run(const char *name, const uint4 *table, uint32_t n_slots, uint32
     return r;
 }
 
+template <int PIECES, int STRIDE>
+static Result run_records(const char *name, const uint4 *table, uint32_t n_slots, int waves_per_simd, uint32_t *sink, int n_cu) {
+    const uint32_t blocks = (uint32_t)(n_cu * waves_per_simd);
+    const uint32_t iters = 4096u;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float ms = 0.0f;
+    for (int rep = 0; rep < 4; rep++) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_records<PIECES, STRIDE>), dim3(blocks), dim3(256), 0, 0, table, n_slots, iters, sink);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (rep == 1 || (rep > 1 && t < ms)) ms = t;
+    }
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+    const double waves = (double)blocks * 4.0;
+    // Glane_per_s counts the 16-byte loads; records per second = that / PIECES
+    Result r{name, 16, 64, waves_per_simd, false, false, ms, waves * 64.0 * iters * PIECES / (ms * 1e-3) / 1e9, waves * iters * PIECES / (ms * 1e-3) / 1e9};
+    return r;
+}
+
 int main(int argc, char **argv) {
     size_t footprint = 6u << 20; // node arrays + triangle records of the 31 k-triangle mesh scene: about 5-6 MB
     bool json = false;
@@ -123,7 +187,7 @@ int main(int argc, char **argv) {
         if (!std::strcmp(argv[i], "--footprint") && i + 1 < argc) footprint = (size_t)std::atoll(argv[++i]);
         else if (!std::strcmp(argv[i], "--json")) json = true;
     }
-    if (footprint < 65536) footprint = 65536;
+    if (footprint < 4096) footprint = 4096;
     if (footprint > ((size_t)1 << 31)) footprint = (size_t)1 << 31;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -154,6 +218,25 @@ int main(int argc, char **argv) {
     rs.push_back(run<16, true, false, 1>("divergent 16 B, dependent chain, 1 of 2 loads in the previous line", table, n_slots, 64, 8, sink, n_cu));
     rs.push_back(run<16, true, false, 3>("divergent 16 B, dependent chain, 3 of 4 loads in the previous line", table, n_slots, 64, 8, sink, n_cu));
     for (int w : {2, 4, 8}) rs.push_back(run<16, true, false, -1>("divergent 16 B, dependent chain of load PAIRS (slot, slot + 1)", table, n_slots, 64, w, sink, n_cu));
+    // records of 32 / 64 bytes fetched by lane pairs / quads: 32 / 16 different records per wave-instruction
+    for (int w : {2, 4, 8}) {
+        rs.push_back(run<16, true, false, 0, 2>("records of 32 B by lane pairs (16 B per lane), dependent chain", table, n_slots, 64, w, sink, n_cu));
+        rs.push_back(run<16, true, false, 0, 4>("records of 64 B by lane quads (16 B per lane), dependent chain", table, n_slots, 64, w, sink, n_cu));
+    }
+    rs.push_back(run<16, false, false, 0, 2>("records of 32 B by lane pairs (16 B per lane), independent", table, n_slots, 64, 8, sink, n_cu));
+    rs.push_back(run<16, false, false, 0, 4>("records of 64 B by lane quads (16 B per lane), independent", table, n_slots, 64, 8, sink, n_cu));
+    rs.push_back(run<16, false, false, 0, 2>("records of 32 B by lane pairs (16 B per lane), independent", table, n_slots, 64, 2, sink, n_cu));
+    rs.push_back(run<16, false, false, 0, 4>("records of 64 B by lane quads (16 B per lane), independent", table, n_slots, 64, 2, sink, n_cu));
+    rs.push_back(run<16, false, false, 0, 8>("records of 128 B by 8 lanes (16 B per lane), independent", table, n_slots, 64, 8, sink, n_cu));
+    rs.push_back(run<16, false, false, 0, 4>("records of 64 B by lane quads, 3 of 4 lanes on, independent", table, n_slots, 48, 8, sink, n_cu));
+    rs.push_back(run<16, false, false>("divergent 16 B, independent", table, n_slots, 64, 2, sink, n_cu));
+    rs.push_back(run<16, false, false>("divergent 16 B, independent", table, n_slots, 64, 4, sink, n_cu));
+    // a lane fetches its record alone, 16 bytes per load
+    rs.push_back(run_records<2, 32>("records of 32 B, one lane each (2 loads), independent", table, n_slots, 8, sink, n_cu));
+    rs.push_back(run_records<3, 48>("records of 48 B packed, one lane each (3 loads), independent", table, n_slots, 8, sink, n_cu));
+    rs.push_back(run_records<3, 64>("records of 48 B in 64 B slots, one lane each (3 loads), independent", table, n_slots, 8, sink, n_cu));
+    rs.push_back(run_records<4, 64>("records of 64 B, one lane each (4 loads), independent", table, n_slots, 8, sink, n_cu));
+    rs.push_back(run_records<1, 16>("records of 16 B, one lane each (1 load), independent", table, n_slots, 8, sink, n_cu));
 
     if (json) {
         std::printf("{\"device\": \"%s\", \"compute_units\": %d, \"footprint_bytes\": %zu, \"peak_divergent_16B_Glane_per_s\": %.2f, \"rows\": [", prop.gcnArchName, n_cu,

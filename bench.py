@@ -81,6 +81,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count-pass", action="store_true", help="skip the untimed BVH work-counting pass (for PMC profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--roulette", action="store_true", help="RT_FLAG_RUSSIAN_ROULETTE, an option the reference does not have: NOT the headline configuration")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: rehearses the N>1 code path")
     args = ap.parse_args()
 
@@ -140,7 +141,8 @@ def main() -> int:
     scene_ms = (time.perf_counter() - t0) * 1e3
 
     plan = rt.plan_shards(args.shard, rank, world, spp, tile_size=64)
-    params = plan.apply(rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_TIMING))
+    extra_flags = rt.FLAG_RUSSIAN_ROULETTE if args.roulette else 0
+    params = plan.apply(rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_TIMING | extra_flags))
 
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
@@ -220,7 +222,7 @@ def main() -> int:
         nodes_per_ray = tris_per_ray = 0.0
         walk_per_ray = {}  # kernel -> (tree nodes visited, tree-leaf triangles tested) per ray of that kernel
         if not args.no_count_pass:
-            cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK)
+            cp = rt.default_params(W, H, spp, shader=shader, seed=1, flags=rt.FLAG_COUNT_WORK | extra_flags)
             cp.spp_begin, cp.spp_end = 0, 1
             scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
             torch.cuda.synchronize()
@@ -396,7 +398,8 @@ def main() -> int:
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {scene_name} {W}x{H} {spp} spp, {shader_name} shader", "shard": args.shard,
+            "config": {"workload": f"{args.workload}: {scene_name} {W}x{H} {spp} spp, {shader_name} shader" + (" + Russian roulette (not the reference's estimator)" if args.roulette else ""),
+                       "shard": args.shard,
                        "rays_per_step": total_rays / steps, "camera_samples_per_step": total_cam / steps,
                        "time_to_image_ms": round(ms_per_step, 2), "scene_upload_ms": round(scene_ms, 2),
                        "cold_time_to_image_ms": round(cold_ms, 1), "device_bytes": int(stats[-1].device_bytes) if stats else 0,

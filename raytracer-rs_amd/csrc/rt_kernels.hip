@@ -1191,7 +1191,11 @@ void launch_shade(const LaunchCfg &cfg, int shader, const DevScene &sc, const Re
     dim3 g(grid), b(BLOCK);
     const bool tab = tables_fit(sc);
     const bool ext = (rc.flags & (RT_FLAG_RUSSIAN_ROULETTE | RT_FLAG_COSINE_DIFFUSE)) != 0u; // options the reference does not have: own instantiations
-    if (ext && shader == RT_SHADER_MIS)
+    if (ext && shader == RT_SHADER_MIS && tab)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, true, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (ext && shader == RT_SHADER_PATH && tab)
+        hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, true, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
+    else if (ext && shader == RT_SHADER_MIS)
         hipLaunchKernelGGL((k_shade<RT_SHADER_MIS, false, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);
     else if (ext && shader == RT_SHADER_PATH)
         hipLaunchKernelGGL((k_shade<RT_SHADER_PATH, false, true>), g, b, 0, cfg.stream, sc, rc, ctl, in, out, hit, sh, planes, n_pixels, cfg.seg_capacity, cfg.shadow_seg_capacity, hb);

@@ -241,6 +241,9 @@ def main() -> int:
             "k_shade": (closest, 48 + 8 + 48 * children_per_node + 40 * shadow_per_node + 12 * adds_per_node + 32 * carry_per_node, sum(s.launches_shade for s in stats),
                         sum(s.ms_shade for s in stats)),
             "k_shadow": (queued, 40 + 12, sum(s.launches_shadow for s in stats), sum(s.ms_shadow for s in stats)),
+            # camera rays written (48 B each).  Its launches run beside the previous iteration's k_shadow on the second stream:
+            # alone (RT_OVERLAP=0) the kernel writes at 6.2 TB/s, see profiles/r3_raygen_alone_vs_overlapped.txt
+            "k_raygen": (cams, 48, sum(s.launches_raygen for s in stats), sum(s.ms_raygen for s in stats)),
         }
         # HBM traffic from the PMC counters is not collected by this run: it comes from the committed counter passes of
         # this same command, and only when they were taken on a library built from the sources in this tree
@@ -268,9 +271,12 @@ def main() -> int:
                                  "bytes_per_unit": round(bpu, 1), "ms_per_step": round(ms / steps, 2)}
         # ---- the walk kernels' own roofline: per-lane ("divergent") 16-byte loads per second.  A visited tree node is one such
         # load, a tested leaf triangle three (its 48-byte record); the scene (a few MB) stays in L2, so these never become
-        # HBM traffic and the HBM figure above says nothing about a walk.  Peak = what tools/ta_rate measures on this GPU for
-        # a table of the scene's footprint: the best rate of per-lane 16-byte buffer loads at random slots, 64 different
-        # cache lines per wave-instruction (independent loads, dependent chains, chains of pairs; 2 to 8 waves per SIMD).
+        # HBM traffic and the HBM figure above says nothing about a walk.  A CU's vector cache keeps nothing of it (measured hit
+        # rate 1 %: thousands of rays per CU, each after another cache line), so every fetch is a line request to the L2, and
+        # loads of one lane that fall into one line (a node and its successor, the three parts of a triangle record) share a
+        # request.  Peak = what tools/ta_rate measures on this GPU for a table of the scene's footprint with exactly those
+        # access shapes: the best of a dependent chain of adjacent load pairs, independent 32-byte records (two loads) and
+        # independent packed 48-byte records (three loads), every lane at a random record of its own.
         info = ds.info
         footprint = info.n_nodes * info.n_orders * 16 + info.n_triangles * 48
         ta = None
@@ -283,7 +289,8 @@ def main() -> int:
             except Exception as e:  # the figure is then simply missing
                 print(f"bench.py: tools/ta_rate failed: {e}", file=sys.stderr)
         if ta:
-            rows16 = [r for r in ta["rows"] if r["bytes"] == 16 and r["what"].startswith("divergent") and r["active_lanes"] == 64]
+            shapes = ("divergent 16 B, dependent chain of load PAIRS", "records of 32 B, one lane each", "records of 48 B packed, one lane each")
+            rows16 = [r for r in ta["rows"] if r["bytes"] == 16 and r["what"].startswith(shapes) and r["active_lanes"] == 64]
             peak_row = max(rows16, key=lambda r: r["Glane_per_s"])
             for name, (n_node, n_tri) in walk_per_ray.items():
                 if name not in kernels or n_node <= 0:

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -95,7 +96,7 @@ struct rt_context {
 
 struct rt_scene {
     rt_context *ctx = nullptr;
-    DevBuf<float4> nodes, tris, tri_nrm, sph, loose;
+    DevBuf<float4> nodes, tris, tri_nrm, sph, loose, loose_boxes;
     DevBuf<uint4> cnodes;
     DevBuf<int2> sph_info, cyl_info;
     DevBuf<int32_t> tri_of_prim;
@@ -581,6 +582,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     }
 
     BvhBuild bvh;
+    int n_cnodes = 0; // nodes per order of the 16-byte copy (the device build thins that copy only)
     const int max_top = (int)env_u32_allow_zero("RT_BVH_TOP", 32);
     const bool ordered = env_u32_allow_zero("RT_BVH_ORDERED", 1) != 0;
     const bool on_device = (flags & RT_SCENE_BVH_ON_DEVICE) != 0 && n_bvh > 0;
@@ -613,8 +615,13 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         if (e == hipSuccess) e = s->tris.ensure(3 * (size_t)d->n_tri);
         std::vector<uint32_t> order((size_t)n_bvh);
         float qp[6] = {0, 0, 0, 1, 1, 1};
+        // thinning of the 16-byte copy (RT_BVH_DEV_WIDEN: per cent of the parent's surface from which a child node is dissolved,
+        // 0 = never; RT_BVH_DEV_PAIRS=0: one triangle per leaf)
+        const float widen = (float)env_u32_allow_zero("RT_BVH_DEV_WIDEN", 60) / 100.0f;
+        const bool pair_leaves = env_u32_allow_zero("RT_BVH_DEV_PAIRS", 1) != 0;
         if (e == hipSuccess)
-            e = build_bvh_device(ctx->stream, bvh_v, bvh_prim, bvh_mat, n_bvh, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp);
+            e = build_bvh_device(ctx->stream, bvh_v, bvh_prim, bvh_mat, n_bvh, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp, widen, pair_leaves,
+                                 &n_cnodes);
         for (int a = 0; a < 3; a++) { bvh.q_lo[a] = qp[a]; bvh.q_scale[a] = qp[3 + a]; }
         if (e != hipSuccess) return cleanup_fail(e, "BVH build on the device");
         // host copy of the triangle records, in the device's leaf order: the primitive -> record table below reads it
@@ -646,6 +653,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     }
     for (int a = 0; a < 3; a++) { s->dev.q_lo[a] = bvh.q_lo[a]; s->dev.q_scale[a] = bvh.q_scale[a]; }
     s->dev.cnodes = s->cnodes.p;
+    s->dev.n_cnodes = on_device ? n_cnodes : bvh.n_nodes;
     {
         hipError_t e = s->tri_nrm.ensure((size_t)std::max(d->n_tri, 1));
         if (e == hipSuccess) {
@@ -723,6 +731,46 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         }
         UP(s->loose, loose.data(), loose.size() / 4, float4);
         s->dev.loose = s->loose.p;
+        // boxes of the loose triangles for the closest-hit scan, padded like the leaves of the tree; triangles with the same
+        // box (the two halves of a quad) share one (RT_LOOSE_BOXES=0: every triangle is tested exactly, one after the other)
+        std::vector<float> lboxes;
+        if (use_loose && by_prim.size() <= 32 && env_u32_allow_zero("RT_LOOSE_BOXES", 1) != 0) {
+            std::vector<std::array<float, 6>> boxes;
+            std::vector<uint32_t> masks;
+            for (size_t j = 0; j < by_prim.size(); j++) {
+                const float *rec = &bvh.tris[12 * (size_t)by_prim[j].second];
+                const float v[3][3] = {{rec[0], rec[1], rec[2]}, {rec[0] + rec[4], rec[1] + rec[5], rec[2] + rec[6]}, {rec[0] + rec[8], rec[1] + rec[9], rec[2] + rec[10]}};
+                std::array<float, 6> bx;
+                float ext = 0.0f, mag = 0.0f;
+                for (int a = 0; a < 3; a++) {
+                    bx[(size_t)a] = std::min(std::min(v[0][a], v[1][a]), v[2][a]);
+                    bx[(size_t)a + 3] = std::max(std::max(v[0][a], v[1][a]), v[2][a]);
+                    ext = std::max(ext, bx[(size_t)a + 3] - bx[(size_t)a]);
+                    mag = std::max(mag, std::max(std::fabs(bx[(size_t)a]), std::fabs(bx[(size_t)a + 3])));
+                }
+                // the record holds v1 - v0 and v2 - v0, so v1 and v2 above carry a rounding error: a wider pad than the tree's
+                const float pad = 2e-4f * ext + 2e-5f * mag + 2e-6f;
+                for (int a = 0; a < 3; a++) { bx[(size_t)a] -= pad; bx[(size_t)a + 3] += pad; }
+                size_t g = 0;
+                for (; g < boxes.size(); g++) {
+                    bool same = true;
+                    for (size_t a = 0; a < 6; a++) same = same && std::fabs(boxes[g][a] - bx[a]) <= pad;
+                    if (same) break;
+                }
+                if (g == boxes.size()) { boxes.push_back(bx); masks.push_back(0u); }
+                else for (size_t a = 0; a < 3; a++) { boxes[g][a] = std::min(boxes[g][a], bx[a]); boxes[g][a + 3] = std::max(boxes[g][a + 3], bx[a + 3]); }
+                masks[g] |= 1u << j;
+            }
+            for (size_t g = 0; g < boxes.size(); g++) {
+                float mbits;
+                std::memcpy(&mbits, &masks[g], 4);
+                const float rec[8] = {boxes[g][0], boxes[g][1], boxes[g][2], mbits, boxes[g][3], boxes[g][4], boxes[g][5], 0.0f};
+                lboxes.insert(lboxes.end(), rec, rec + 8);
+            }
+        }
+        UP(s->loose_boxes, lboxes.data(), lboxes.size() / 4, float4);
+        s->dev.loose_boxes = s->loose_boxes.p;
+        s->dev.n_loose_boxes = (int32_t)(lboxes.size() / 8);
         // primitive id -> triangle record, for the walk that merges hits by (t, primitive id)
         std::vector<int32_t> tri_of_prim((size_t)std::max(prim, 1), -1);
         for (int i = 0; i < d->n_tri; i++) {
@@ -750,6 +798,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    s->loose_boxes.release();
     s->nodes.release(); s->cnodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
     s->tri_nrm.release(); s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
     delete s;

@@ -136,9 +136,26 @@ __global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *
     if (i == 0) parent[0] = -1;
 }
 
+// Node flags of the thinned tree (the 16-byte copy)
+#define NF_DISSOLVED 1u /* inner node: its children stand in its parent's child list, the node itself is not emitted */
+#define NF_PAIR 2u      /* inner node over two leaves: emitted as ONE leaf of two triangles */
+#define NF_DEAD 4u      /* leaf under such a node: not emitted */
+#define NF_WIDE 8u      /* inner node that has taken a dissolved child's children: not dissolved itself (at most four children) */
+
+__device__ __forceinline__ float box_area(const volatile Box6 *b) {
+    const float dx = b->mx[0] - b->mn[0], dy = b->mx[1] - b->mn[1], dz = b->mx[2] - b->mn[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
 // bottom-up: the second thread to arrive at an inner node owns it.  Release before the counter, acquire after it: the
-// children's boxes were written by other compute units.
-__global__ __launch_bounds__(BB) void k_bvh_refit(int n, const int2 *children, const int *parent, int *arrived, Box6 *nbox) {
+// children's boxes (and sizes) were written by other compute units.  Besides the box the owner decides how its children
+// appear in the thinned tree — a child node whose surface exceeds `widen` x the node's own is dissolved (the host
+// builder's rule for two children: a box test that fails less than half the time costs more than it saves), unless that
+// child has itself taken in a dissolved node's children (chains of dissolved nodes would make lists of dozens of boxes,
+// each tested by every ray that meets the first: measured 3x slower) — and counts the nodes of its thinned subtree,
+// itself included: sz.
+__global__ __launch_bounds__(BB) void k_bvh_refit(int n, const int2 *children, const int *parent, int *arrived, Box6 *nbox, int *sz, unsigned char *flags,
+                                                  float widen, int pair_leaves) {
     const int j = blockIdx.x * BB + threadIdx.x;
     if (j >= n) return;
     int cur = parent[(n - 1) + j];
@@ -154,6 +171,33 @@ __global__ __launch_bounds__(BB) void k_bvh_refit(int n, const int2 *children, c
             u.mx[k] = fmaxf(a->mx[k], b->mx[k]);
         }
         nbox[cur] = u;
+        const bool leaf_a = c.x >= n - 1, leaf_b = c.y >= n - 1;
+        if (pair_leaves && leaf_a && leaf_b) {
+            flags[cur] = NF_PAIR;
+            flags[c.x] = NF_DEAD;
+            flags[c.y] = NF_DEAD;
+            sz[cur] = 1;
+        } else {
+            const float area = 2.0f * ((u.mx[0] - u.mn[0]) * (u.mx[1] - u.mn[1]) + (u.mx[1] - u.mn[1]) * (u.mx[2] - u.mn[2]) + (u.mx[2] - u.mn[2]) * (u.mx[0] - u.mn[0]));
+            int total = 1;
+            unsigned wide = 0u;
+            const int ch[2] = {c.x, c.y};
+            for (int k = 0; k < 2; k++) {
+                if (ch[k] >= n - 1) { total += 1; continue; }
+                const volatile unsigned char *fp = &flags[ch[k]];
+                const volatile int *sp = &sz[ch[k]];
+                const unsigned char f = *fp;
+                if (!(f & (NF_PAIR | NF_WIDE)) && widen > 0.0f && box_area(&nbox[ch[k]]) > widen * area) {
+                    flags[ch[k]] = (unsigned char)(f | NF_DISSOLVED);
+                    total += *sp - 1;
+                    wide = NF_WIDE;
+                } else {
+                    total += *sp;
+                }
+            }
+            flags[cur] = (unsigned char)wide;
+            sz[cur] = total;
+        }
         cur = parent[cur];
     }
 }
@@ -211,24 +255,37 @@ __global__ __launch_bounds__(BB) void k_bvh_thread(int n, int n_orders, const in
     dst[1] = make_float4(nz ? b.mx[2] : b.mn[2], nz ? b.mn[2] : b.mx[2], __int_as_float(link), __int_as_float(miss));
 }
 
-// The 16-byte copy of the tree (layout: rt_bvh.h): per order, node `idx` goes to its position in that order's depth-first
-// sequence — one more than its parent's position, plus the whole subtree of the sibling if that one is visited first —
-// with its planes quantised to 16 bits over the root box, one step outwards, and the position to go on with after a miss
-// (its own position + the size of its subtree).  An inner node over leaves [a, b] has 2 (b - a) + 1 nodes below and including it.
+// The 16-byte copy of the tree (layout: rt_bvh.h), thinned: per order, a node that is emitted goes to its position in that
+// order's depth-first sequence — the number of emitted nodes before it: per ancestor one if the ancestor is emitted, plus
+// the thinned subtree of the sibling if that one is visited first — with its planes quantised to 16 bits over the root
+// box, one step outwards, and the position to go on with after a miss (its own position + the size of its thinned
+// subtree).  `stride` = sz[0], the number of emitted nodes.
 __global__ __launch_bounds__(BB) void k_bvh_compact(int n, int n_orders, const int2 *children, const int *parent, const unsigned char *swap_mask,
-                                                    const int2 *range, const Box6 *nbox, uint4 *cnodes, float *q_params) {
+                                                    const int2 *range, const Box6 *nbox, const int *sz, const unsigned char *flags, int stride, uint4 *cnodes,
+                                                    float *q_params) {
     const int nn = 2 * n - 1;
     const long long g = (long long)blockIdx.x * BB + threadIdx.x;
     if (g >= (long long)nn * n_orders) return;
     const int k = (int)(g / nn), idx = (int)(g - (long long)k * nn);
     const int ko = n_orders == 8 ? k : 0;
-    auto size_of = [&](int c) { return c >= n - 1 ? 1 : 2 * (range[c].y - range[c].x) + 1; };
+    if (g == 0) {
+        const Box6 root = nbox[0];
+        for (int a = 0; a < 3; a++) {
+            const float ext = root.mx[a] - root.mn[a];
+            q_params[a] = root.mn[a];
+            q_params[3 + a] = ext > 0.0f ? ext / 65535.0f : 1.0f;
+        }
+    }
+    const unsigned char f = flags[idx];
+    if (f & (NF_DISSOLVED | NF_DEAD)) return; // not emitted
+    // emitted nodes under and including c, as its parent's list sees it
+    auto size_of = [&](int c) { return c >= n - 1 ? ((flags[c] & NF_DEAD) ? 0 : 1) : sz[c] - ((flags[c] & NF_DISSOLVED) ? 1 : 0); };
     int pos = 0, cur = idx;
     for (int p = parent[cur]; p >= 0; p = parent[cur]) {
         const int2 c = children[p];
         const bool sw = (swap_mask[p] >> ko) & 1;
         const int first = sw ? c.y : c.x;
-        pos += 1 + (cur == first ? 0 : size_of(first));
+        pos += ((flags[p] & NF_DISSOLVED) ? 0 : 1) + (cur == first ? 0 : size_of(first));
         cur = p;
     }
     const Box6 root = nbox[0], b = nbox[idx];
@@ -236,14 +293,16 @@ __global__ __launch_bounds__(BB) void k_bvh_compact(int n, int n_orders, const i
     for (int a = 0; a < 3; a++) {
         const float ext = root.mx[a] - root.mn[a];
         const float scale = ext > 0.0f ? ext / 65535.0f : 1.0f;
-        if (g == 0) { q_params[a] = root.mn[a]; q_params[3 + a] = scale; }
         const float lo = floorf((b.mn[a] - root.mn[a]) / scale) - 1.0f, hi = ceilf((b.mx[a] - root.mn[a]) / scale) + 1.0f;
         const uint32_t qlo = (uint32_t)fminf(fmaxf(lo, 0.0f), 65535.0f), qhi = (uint32_t)fminf(fmaxf(hi, 0.0f), 65535.0f);
         const bool neg = n_orders == 8 && ((k >> a) & 1);
         w[a] = neg ? (qhi | (qlo << 16)) : (qlo | (qhi << 16));
     }
-    const uint32_t last = idx < n - 1 ? (uint32_t)(pos + size_of(idx)) : (0x80000000u | (uint32_t)((idx - (n - 1)) * 8));
-    cnodes[(size_t)k * (size_t)nn + (size_t)pos] = make_uint4(w[0], w[1], w[2], last);
+    uint32_t last;
+    if (idx >= n - 1) last = 0x80000000u | (uint32_t)((idx - (n - 1)) * 8);
+    else if (f & NF_PAIR) last = 0x80000000u | (uint32_t)(range[idx].x * 8 + 1); // two triangles, neighbours in sorted order
+    else last = (uint32_t)(pos + sz[idx]);
+    cnodes[(size_t)k * (size_t)stride + (size_t)pos] = make_uint4(w[0], w[1], w[2], last);
 }
 
 __global__ void k_bvh_init_bounds(int *bounds) {
@@ -265,7 +324,9 @@ inline unsigned grid_for(long long n) { return (unsigned)((n + BB - 1) / BB); }
     } while (0)
 
 hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const int32_t *prim_host, const int32_t *mat_host, int n, bool ordered,
-                            float4 *nodes_dev, uint4 *cnodes_dev, float4 *tris_dev, uint32_t *order_host, float *q_params_host) {
+                            float4 *nodes_dev, uint4 *cnodes_dev, float4 *tris_dev, uint32_t *order_host, float *q_params_host, float widen,
+                            bool pair_leaves, int *n_cnodes) {
+    if (n_cnodes) *n_cnodes = 0;
     if (n <= 0) return hipSuccess;
     const int nn = 2 * n - 1, n_orders = ordered ? 8 : 1;
     float *tri_v = nullptr, *centroid = nullptr;
@@ -275,11 +336,12 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     int *bounds = nullptr, *parent = nullptr, *arrived = nullptr;
     int2 *children = nullptr, *range = nullptr;
     float *q_params = nullptr;
-    unsigned char *swap_mask = nullptr;
+    unsigned char *swap_mask = nullptr, *flags = nullptr;
+    int *sz = nullptr;
     void *sort_tmp = nullptr;
     auto cleanup = [&]() {
         for (void *p : {(void *)tri_v, (void *)centroid, (void *)prim, (void *)mat, (void *)tbox, (void *)nbox, (void *)keys_in, (void *)keys_out, (void *)bounds,
-                        (void *)parent, (void *)arrived, (void *)children, (void *)range, (void *)q_params, (void *)swap_mask, sort_tmp})
+                        (void *)parent, (void *)arrived, (void *)children, (void *)range, (void *)q_params, (void *)swap_mask, (void *)flags, (void *)sz, sort_tmp})
             if (p) (void)hipFree(p);
     };
     BVH_TRY(hipMalloc((void **)&tri_v, 9 * sizeof(float) * (size_t)n));
@@ -297,6 +359,8 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     BVH_TRY(hipMalloc((void **)&range, sizeof(int2) * (size_t)n));
     BVH_TRY(hipMalloc((void **)&q_params, 6 * sizeof(float)));
     BVH_TRY(hipMalloc((void **)&swap_mask, (size_t)n));
+    BVH_TRY(hipMalloc((void **)&flags, (size_t)nn));
+    BVH_TRY(hipMalloc((void **)&sz, sizeof(int) * (size_t)nn));
     size_t sort_bytes = 0;
     BVH_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys_out, n, 0, 62, stream));
     BVH_TRY(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
@@ -305,6 +369,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     BVH_TRY(hipMemcpyAsync(prim, prim_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
     BVH_TRY(hipMemcpyAsync(mat, mat_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, stream));
     BVH_TRY(hipMemsetAsync(arrived, 0, sizeof(int) * (size_t)n, stream));
+    BVH_TRY(hipMemsetAsync(flags, 0, (size_t)nn, stream));
     hipLaunchKernelGGL(k_bvh_init_bounds, dim3(1), dim3(64), 0, stream, bounds);
     hipLaunchKernelGGL(k_bvh_prepare, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, n, tbox, centroid, bounds);
     hipLaunchKernelGGL(k_bvh_keys, dim3(grid_for(n)), dim3(BB), 0, stream, centroid, n, bounds, keys_in);
@@ -312,7 +377,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     hipLaunchKernelGGL(k_bvh_emit_tris, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, prim, mat, keys_out, n, tbox, tris_dev, nbox);
     if (n > 1) {
         hipLaunchKernelGGL(k_bvh_hierarchy, dim3(grid_for(n - 1)), dim3(BB), 0, stream, keys_out, n, children, parent, range);
-        hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox);
+        hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox, sz, flags, widen, pair_leaves ? 1 : 0);
         hipLaunchKernelGGL(k_bvh_order, dim3(grid_for(n - 1)), dim3(BB), 0, stream, n, children, nbox, swap_mask);
     } else {
         const int minus_one = -1;
@@ -320,8 +385,16 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
         BVH_TRY(hipStreamSynchronize(stream)); // minus_one goes out of scope
     }
     hipLaunchKernelGGL(k_bvh_thread, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, nbox, nodes_dev);
-    hipLaunchKernelGGL(k_bvh_compact, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, range, nbox, cnodes_dev,
-                       q_params);
+    // the size of the thinned tree = the stride of its arrays: known once the bottom-up pass is through
+    int stride = 1;
+    if (n > 1) {
+        BVH_TRY(hipMemcpyAsync(&stride, sz, sizeof(int), hipMemcpyDeviceToHost, stream));
+        BVH_TRY(hipStreamSynchronize(stream));
+        if (stride < 1 || stride > nn) { cleanup(); return hipErrorUnknown; }
+    }
+    if (n_cnodes) *n_cnodes = stride;
+    hipLaunchKernelGGL(k_bvh_compact, dim3(grid_for((long long)nn * n_orders)), dim3(BB), 0, stream, n, n_orders, children, parent, swap_mask, range, nbox, sz, flags,
+                       stride, cnodes_dev, q_params);
     BVH_TRY(hipGetLastError());
     BVH_TRY(hipMemcpyAsync(q_params_host, q_params, 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
     // the sorted order goes back to the host: it needs to know where each triangle's record went

@@ -124,6 +124,7 @@ struct DevScene {
     // the same tree in 16-byte nodes, one array per order, each in its own depth-first sequence (layout: rt_bvh.h); the
     // planes are quantised to 16 bits over the root box: plane = q_lo + q * q_scale
     const uint4 *cnodes;
+    int32_t n_cnodes; // nodes per order in cnodes (the tree built on the GPU drops nodes there that it keeps in `nodes`)
     float q_lo[3], q_scale[3];
     const float4 *nodes;
     const float4 *tris;
@@ -147,6 +148,11 @@ struct DevScene {
     // loop the whole wave runs together (the reference's own scan of the world list, hitable.rs:44-50) instead of walking the BVH.
     const float4 *loose;
     int32_t n_loose;
+    // Padded boxes of the loose triangles, one per group of triangles with the same box (the two halves of a wall):
+    // (min.xyz, the group's triangles as a bit mask), (max.xyz, 0).  A closest-hit ray tests the boxes first, every lane in
+    // step, and runs the exact triangle test only for the triangles whose box it meets, each lane for its own.
+    const float4 *loose_boxes;
+    int32_t n_loose_boxes;
     // light shadow rays (they can only meet the loose triangles, spheres and cylinders) are answered by the shading
     // kernel itself instead of going through the shadow queue when set (and n_loose >= 0)
     int32_t inline_shadow;
@@ -496,7 +502,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                                            float t_min, float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t NONE = 0xFFFFFFFFu;
-    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.cnodes, (uint32_t)sc.n_nodes * (uint32_t)sc.n_orders * 16u);
+    const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.cnodes, (uint32_t)sc.n_cnodes * (uint32_t)sc.n_orders * 16u);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
     const bool presorted = sc.n_orders == 8;
@@ -546,7 +552,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 *leaf = (inside && is_leaf) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
                 // depth-first order: the first child of an inner node and the successor of a leaf are the next node
                 const uint32_t nxt = (inside || is_leaf) ? (uint32_t)at + 1u : nd.w;
-                return nxt < (uint32_t)sc.n_nodes ? (int)nxt : -1;
+                return nxt < (uint32_t)sc.n_cnodes ? (int)nxt : -1;
             };
             auto push_leaves = [&](int leaf) { // every lane of the wave calls it
                 const unsigned long long m = __ballot(leaf >= 0);
@@ -656,12 +662,12 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 // the octant is taken from the SIGN BITS (a component of -0 has a reciprocal of -inf): it decides which of a
                 // node's two planes per axis is the entry plane, and must agree with the sign of the reciprocal
                 const uint32_t octant = presorted ? ((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2)) : 0u;
-                g_base = octant * (uint32_t)sc.n_nodes * 16u;
+                g_base = octant * (uint32_t)sc.n_cnodes * 16u;
                 wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
                 wl.ray_b[lane] = make_float2(d.y, d.z);
                 wl.best[lane] = (ANY_HIT && !walk) ? 0ull : k_init;
                 cull_t = ANY_HIT ? t_max : init.t;
-                node = (walk && sc.n_nodes > 0) ? 0 : -1;
+                node = (walk && sc.n_cnodes > 0) ? 0 : -1;
                 pushed = false;
             }
             next = uni(next + min((uint32_t)__popcll(free_m), remaining));
@@ -673,8 +679,9 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
 
 // The loose triangles, one after the other, for a ray that misses the boxes of all big meshes.  The loop is the same for
 // every lane of the wave (no divergent walk) and the triangle data is uniform, so the loads are scalar.
+// `staged`: the workgroup's LDS copy of the 3 * n_loose record words (closest hit only), or nullptr.
 template <bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_scan) {
+__device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d, float t_min, float t_max, uint32_t *n_scan, const float4 *staged = nullptr) {
     TriHit best{t_max, -1, -1};
     auto test = [&](int k) { // exact test of loose triangle k; true = an occlusion query is answered
         const float4 a = sc.loose[3 * k], b = sc.loose[3 * k + 1], c = sc.loose[3 * k + 2];
@@ -718,6 +725,48 @@ __device__ __forceinline__ TriHit loose_traverse(const DevScene &sc, F3 o, F3 d,
         }
         return best;
     }
+    if (!ANY_HIT && sc.n_loose_boxes > 0) {
+        // Closest hit.  A ray in a room meets one or two of the triangles around it, and a wave running the exact test
+        // (50 instructions with its IEEE division) for every triangle in turn spends most of them on misses.  The boxes
+        // only cull (padded like the leaves of the tree, exit distance widened, NaN distances of a zero direction
+        // component dropped by min / max), so the result is the exact tests' own.
+        const float ix = rcp_w(d.x), iy = rcp_w(d.y), iz = rcp_w(d.z);
+        const float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
+        uint32_t cand = 0u;
+        for (int g = 0; g < sc.n_loose_boxes; g++) {
+            const float4 lo = sc.loose_boxes[2 * g], hi = sc.loose_boxes[2 * g + 1]; // (scalar loads: g is the same for every lane)
+            const float x0 = __builtin_fmaf(lo.x, ix, ox), x1 = __builtin_fmaf(hi.x, ix, ox);
+            const float y0 = __builtin_fmaf(lo.y, iy, oy), y1 = __builtin_fmaf(hi.y, iy, oy);
+            const float z0 = __builtin_fmaf(lo.z, iz, oz), z1 = __builtin_fmaf(hi.z, iz, oz);
+            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+            if (tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f)) cand |= __float_as_uint(lo.w);
+        }
+        while (__ballot(cand != 0u) != 0ull) { // every lane its own next candidate, in primitive order
+            if (cand != 0u) {
+                const int k = __ffs((int)cand) - 1;
+                cand &= cand - 1u;
+                // a lane's own triangle: from LDS when the workgroup staged the list (two load sites, so that each is compiled
+                // for its own address space: one site reading through either pointer becomes a flat load)
+                float4 a, b, c;
+                if (staged) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const __attribute__((address_space(3))) f32x4 *ls = (const __attribute__((address_space(3))) f32x4 *)staged; // LDS: ds_read, not flat
+                    const f32x4 va = ls[3 * k], vb = ls[3 * k + 1], vc = ls[3 * k + 2];
+                    a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w); c = make_float4(vc.x, vc.y, vc.z, vc.w);
+                } else { a = sc.loose[3 * k]; b = sc.loose[3 * k + 1]; c = sc.loose[3 * k + 2]; }
+                if (COUNT) (*n_scan)++;
+                float t;
+                if (tri_hit(f3(a.x, a.y, a.z), f3(b.x, b.y, b.z), f3(c.x, c.y, c.z), o, d, t_min, t_max, false, &t)) {
+                    const int prim = __float_as_int(a.w);
+                    if (t < best.t || (t == best.t && prim > best.prim)) {
+                        best.t = t; best.tri = __float_as_int(c.w); best.prim = prim;
+                    }
+                }
+            }
+        }
+        return best;
+    }
     for (int k = 0; k < sc.n_loose; k++) {
         if (test(k)) break;
     }
@@ -733,7 +782,8 @@ __device__ __forceinline__ void world_hit(const DevScene &sc, const float4 *lds_
                                           int *code_out, int *prim_out, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *n_scan = nullptr) {
     TriHit th{t_max, -1, -1};
     uint32_t scan_local = 0; // (work counting: tests of the scanned list go to n_scan, tests of tree leaves to n_tris)
-    if (LOOSE_ONLY || sc.n_loose >= 0) th = loose_traverse<false, COUNT>(sc, o, d, t_min, t_max, &scan_local);
+    // (LOOSE_ONLY: no node cache is in use, and lds_nodes, when given, is the workgroup's copy of the loose records)
+    if (LOOSE_ONLY || sc.n_loose >= 0) th = loose_traverse<false, COUNT>(sc, o, d, t_min, t_max, &scan_local, LOOSE_ONLY ? lds_nodes : nullptr);
     if (COUNT && n_scan) *n_scan += scan_local;
     if (!LOOSE_ONLY) {
         // a tree triangle at exactly the loose hit's distance is still accepted (geometry.rs:53) and wins with the larger id

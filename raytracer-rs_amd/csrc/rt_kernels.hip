@@ -375,13 +375,18 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
     if (bx * BLOCK >= n_seg) return;
     const bool loose = seg < RT_NSEG_HALF && sc.n_loose >= 0; // light rays scan the few triangles outside the big meshes
     if (USE_LDS && !loose) fill_top_cache<BLOCK>(sc, lds_nodes);
+    const bool stage_loose = loose && sc.n_loose_boxes > 0; // every lane fetches its own candidates: from LDS (read only when staged)
+    if (stage_loose) {
+        if (threadIdx.x < 3u * (uint32_t)sc.n_loose) lds_nodes[threadIdx.x] = sc.loose[threadIdx.x];
+        __syncthreads();
+    }
     if (il >= n_seg) return;
     const F3 o = f3(a.x, a.y, a.z), d = f3(a.w, b.x, b.y);
     float t_obj;
     int code, prim;
     uint32_t nn = 0, nt = 0, ns = 0;
     // light rays (first half of the segments) postpone their leaves, heavy rays do not: see bvh_traverse
-    if (loose) world_hit<COUNT, false, false, true>(sc, nullptr, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
+    if (loose) world_hit<COUNT, false, false, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
     else if (seg < RT_NSEG_HALF) world_hit<COUNT, USE_LDS, true>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
     else world_hit<COUNT, USE_LDS, false>(sc, lds_nodes, o, d, rc.t_min, rc.t_max, &t_obj, &code, &prim, &nn, &nt, &ns);
     hit[i] = make_float2(t_obj, __int_as_float(code));

@@ -22,6 +22,11 @@ source is a JPEG the reference's authors rendered with the scene constructor nam
         jittered / blue (DiskLight::visible, src/light.rs:150-181).  Stored in LINEAR units ((v / 255.99)^2 averaged):
         the test compares ratios, see tests/test_oracle_reference_renders.py
 
+  output/path1.jpg                              <- the box with the chess board and the TWO coloured disk lights of
+        src/scene.rs:333-344, mirror sphere, pyramid, cylinder, teapot and the two figure meshes the repository lacks;
+        the file name and its noise say path_trace_shader (src/shader.rs:58-90), and so do the levels: see the test.  Linear
+        units, regions the figures neither cover nor shadow
+
 Stored: for the deterministic chessboard renders the 200x200 image itself (centre 4x4 of every 8x8 block, averaged);
 for everything else block means on a coarse grid, or means of hand-picked regions.
 """
@@ -140,6 +145,12 @@ meta["cornell_disk_whitted_linear"] = {}
 for sampler, fname in {"white": "white_16spp.jpg", "uniform": "uniform_16spp.jpg", "jittered": "jigger_16spp.jpg", "blue": "blue_16spp.jpg"}.items():
     meta["cornell_disk_whitted_linear"][sampler] = region_means(load("sampling/cornell/1light/" + fname), WHITTED_REGIONS, linear=True)
 meta["sources"]["cornell_disk_whitted_linear"] = "sampling/cornell/1light/*_16spp.jpg"
+
+# ---- two disk lights, plain path tracing: the left wall, the back wall's white squares under the ceiling, the ceiling
+PATH1_REGIONS = {"left_wall_up": (0.03, 0.25, 0.12, 0.45), "back_white_top": (0.405, 0.205, 0.44, 0.24), "ceiling_mid": (0.40, 0.02, 0.50, 0.06),
+                 "ceiling_front_left": (0.08, 0.03, 0.16, 0.08), "floor_front": (0.35, 0.93, 0.65, 0.98), "right_wall_up": (0.88, 0.25, 0.97, 0.45)}
+meta["path1_linear"] = region_means(load("path1.jpg"), PATH1_REGIONS, linear=True)
+meta["sources"]["path1_linear"] = "path1.jpg"
 
 np.savez_compressed(os.path.join(HERE, "reference_renders.npz"), **arrays)
 with open(os.path.join(HERE, "reference_renders.json"), "w") as f:

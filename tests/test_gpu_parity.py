@@ -806,6 +806,27 @@ def test_gpu_disk_light_box_matches_the_reference_renders(rt, gpu_ctx, golden_di
         ds.close()
 
 
+def test_gpu_two_disk_lights_under_the_plain_path_tracer(rt, gpu_ctx, golden_dir):
+    """output/path1.jpg on the HIP path: k_shade<RT_SHADER_PATH> (src/shader.rs:58-90) in the box with the two coloured
+    disk lights, against the levels of the reference's own render where direct light dominates (the red wall, the white
+    squares of the back wall under the ceiling); see tests/test_oracle_reference_renders.py for what the other regions
+    carry."""
+    import json
+
+    regs = json.load(open(os.path.join(golden_dir, "reference_renders.json")))["path1_linear"]
+    hs = rt.HostScene("cornell_2light", 1.0, light_sampler=rt.SAMPLER_BLUE)
+    ds = rt.DeviceScene(gpu_ctx, hs.desc)
+    spp = 1024
+    acc, _ = ds.render(hs.camera, rt.default_params(400, 400, spp, shader=rt.SHADER_PATH, seed=2))
+    lin = acc / spp
+    r = {name: _region_mean(lin, v["box"]) / np.maximum(np.array(v["mean_rgb"]), 1e-4) for name, v in regs.items()}
+    assert 0.93 < r["left_wall_up"][0] < 1.2, r["left_wall_up"]
+    assert (r["back_white_top"] > 0.78).all() and (r["back_white_top"] < 1.2).all(), r["back_white_top"]
+    for name in ("ceiling_mid", "ceiling_front_left", "floor_front"):
+        assert (r[name] > 0.65).all() and (r[name] < 1.45).all(), (name, r[name])
+    ds.close()
+
+
 # ---- the acceleration structure built on the GPU ------------------------------------------------------------------------
 @pytest.mark.parametrize("loose_max", ["16", "0"])
 @pytest.mark.parametrize("scene,W,H", [("utah", 160, 90), ("miku", 160, 90), ("composite", 96, 54), ("blue_noise_test", 64, 64), ("head", 48, 48)])

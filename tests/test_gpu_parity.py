@@ -167,7 +167,8 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
 
 
 KNOBS = [{"RT_CARRY": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "2", "RT_TAIL": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "0"}, {"RT_CARRY": "1", "RT_INLINE_SHADOW": "1", "RT_QUEUE_TARGET": "30000"}, {"RT_DEFERRED": "0"}, {"RT_WALK_SPAN": "1"}, {"RT_WALK_SPAN": "16", "RT_QUEUE_TARGET": "100000"}, {"RT_INLINE_SHADOW": "0"}, {"RT_INLINE_SHADOW": "2"}, {"RT_INLINE_SHADOW": "2", "RT_LOOSE_MAX": "0"}, {"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
-         {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"}]
+         {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"},
+         {"RT_LOOSE_BOXES": "0"}, {"RT_LOOSE_BOXES": "0", "RT_INLINE_SHADOW": "0", "RT_CARRY": "0"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
@@ -808,22 +809,31 @@ def test_gpu_disk_light_box_matches_the_reference_renders(rt, gpu_ctx, golden_di
 
 def test_gpu_two_disk_lights_under_the_plain_path_tracer(rt, gpu_ctx, golden_dir):
     """output/path1.jpg on the HIP path: k_shade<RT_SHADER_PATH> (src/shader.rs:58-90) in the box with the two coloured
-    disk lights, against the levels of the reference's own render where direct light dominates (the red wall, the white
-    squares of the back wall under the ceiling); see tests/test_oracle_reference_renders.py for what the other regions
-    carry."""
+    disk lights explains the reference's own render up to one factor per colour channel (spread over wall, back wall,
+    ceiling and floor below 1.45), k_shade<RT_SHADER_MIS> does not (above 1.6): see
+    tests/test_oracle_reference_renders.py for the measured ratios and what they mean."""
     import json
 
     regs = json.load(open(os.path.join(golden_dir, "reference_renders.json")))["path1_linear"]
     hs = rt.HostScene("cornell_2light", 1.0, light_sampler=rt.SAMPLER_BLUE)
     ds = rt.DeviceScene(gpu_ctx, hs.desc)
-    spp = 1024
-    acc, _ = ds.render(hs.camera, rt.default_params(400, 400, spp, shader=rt.SHADER_PATH, seed=2))
-    lin = acc / spp
-    r = {name: _region_mean(lin, v["box"]) / np.maximum(np.array(v["mean_rgb"]), 1e-4) for name, v in regs.items()}
-    assert 0.93 < r["left_wall_up"][0] < 1.2, r["left_wall_up"]
-    assert (r["back_white_top"] > 0.78).all() and (r["back_white_top"] < 1.2).all(), r["back_white_top"]
-    for name in ("ceiling_mid", "ceiling_front_left", "floor_front"):
-        assert (r[name] > 0.65).all() and (r[name] < 1.45).all(), (name, r[name])
+
+    def spreads(shader, spp):
+        acc, _ = ds.render(hs.camera, rt.default_params(400, 400, spp, shader=shader, seed=2))
+        lin = acc / spp
+        r = {name: _region_mean(lin, v["box"]) / np.maximum(np.array(v["mean_rgb"]), 1e-4) for name, v in regs.items()}
+        out = []
+        for c in range(3):
+            names = ["back_white_top", "ceiling_mid", "ceiling_front_left", "floor_front"] + (["left_wall_up"] if c == 0 else [])
+            v = np.array([r[n][c] for n in names])
+            out.append((v.max() / v.min(), float(np.median(v))))
+        return out
+
+    sp = spreads(rt.SHADER_PATH, 2048)
+    for (spread, med), (lo, hi) in zip(sp, [(1.05, 1.4), (0.72, 0.95), (1.05, 1.4)]):
+        assert spread < 1.45 and lo < med < hi, sp
+    sm = spreads(rt.SHADER_MIS, 512)
+    assert all(spread > 1.6 for spread, _ in sm), sm
     ds.close()
 
 
@@ -885,3 +895,27 @@ def test_device_built_bvh_edge_cases(rt, orc, gpu_ctx, monkeypatch):
         ca, _ = orc.OracleScene(sc.desc, 0, sc).render(cam, p)
         assert_radiance_close(ga, ca)
         ds.close()
+
+
+@pytest.mark.parametrize("env", [{"RT_BVH_DEV_WIDEN": "0", "RT_BVH_DEV_PAIRS": "0"}, {"RT_BVH_DEV_WIDEN": "0"}, {"RT_BVH_DEV_PAIRS": "0"},
+                                 {"RT_BVH_DEV_WIDEN": "35"}, {"RT_BVH_DEV_WIDEN": "90", "RT_LOOSE_MAX": "0"}, {"RT_BVH_DEV_WIDEN": "50", "RT_BVH_ORDERED": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_device_built_bvh_thinned_in_any_way_gives_the_same_image(rt, orc, gpu_ctx, monkeypatch, env):
+    """The 16-byte copy of the GPU-built tree with and without two-triangle leaves and dissolved nodes, at several
+    thresholds: another tree each time, the same closest hits (heavy rays walk that copy), the same image as the host tree."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H = 96, 54
+    for scene in ("miku", "utah"):
+        hs = rt.HostScene(scene, W / H)
+        host = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=False)
+        dev = rt.DeviceScene(gpu_ctx, hs.desc, bvh_on_device=True)
+        p = rt.default_params(W, H, 3, seed=9)
+        da, dst = dev.render(hs.camera, p)
+        ha, hst = host.render(hs.camera, p)
+        assert (dst.rays_closest, dst.rays_shadow) == (hst.rays_closest, hst.rays_shadow)
+        assert_radiance_close(da, ha, rel=1e-5)
+        ca, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, p)
+        assert_radiance_close(da, ca)
+        host.close()
+        dev.close()

@@ -199,30 +199,40 @@ def test_whitted_disk_light_estimate_has_the_reference_s_shape(rt, orc, ref, sam
     assert 3.15 < np.median(ratios) < 3.55, ratios  # measured medians: 3.25 (uniform grid on the disk), 3.42 (the three random samplers)
 
 
+def channel_spreads(ratios):
+    """Per colour channel: (largest / smallest, median) of the ratios over the regions that have light in that channel."""
+    out = []
+    for c in range(3):
+        names = ["back_white_top", "ceiling_mid", "ceiling_front_left", "floor_front"] + (["left_wall_up"] if c == 0 else [])
+        v = np.array([ratios[n][c] for n in names])
+        out.append((v.max() / v.min(), float(np.median(v))))
+    return out
+
+
 def test_two_disk_lights_under_the_plain_path_tracer(rt, orc, ref):
     """output/path1.jpg: the box with the chess board and the two coloured disk lights of src/scene.rs:333-344 under
     path_trace_shader (src/shader.rs:58-90: scatter_d, attenuation, no next-event estimation — light is found only by
-    hitting it, DiskLight::hit).  Nothing records which shader made the file; its levels do: with the plain path tracer
-    the oracle is within 7 % on the red wall and within 15 % in every channel on the white squares under the ceiling,
-    with path_trace_shader_mis (whose estimator has another expectation: no cosine on the scattered branch, 1/pi as the
-    density, src/material.rs:454-484) it is 30 % too dark on the wall and 40-70 % too bright on the floor.  Surfaces lit
-    mostly by bounces (ceiling, floor) carry what the render's other differences do to the indirect light — the two
-    absent figure meshes (a mirror and a glass one) and the right wall, whose green was 1.7x as bright then as (0, 0.4, 0)
-    of src/scene.rs:135 gives (the albedo changed afterwards, as in mis_40spp.jpg): they are held to 0.65..1.45."""
+    hitting it, DiskLight::hit).  Nothing records which shader made the file; the balance between its surfaces does.
+    Measured on the GPU at 4096 samples (linear ratios ours / render; left wall, white square under the ceiling, two
+    ceiling regions, floor): plain path tracer R 1.09 1.18 1.30 1.30 1.36, G 0.85 0.74 0.84 0.90, B 1.24 1.25 1.39 1.03 —
+    ONE factor per channel (1.2, 0.83, 1.2: the lights' colours at the time, the file is older than HEAD) with a spread
+    below 1.4; path_trace_shader_mis R 0.73 0.92 0.98 1.03 1.52, G 0.79 0.64 0.76 1.46, B 1.08 1.18 1.34 1.85 — the
+    floor twice as bright against the walls, a spread of 1.7 to 2.3: its estimator has another expectation (no cosine
+    on the scattered branch, 1/pi as density, src/material.rs:454-484).  Held: the spread per channel under the path shader,
+    its medians, and that the MIS shader does not fit.  The factors themselves are reported, not tuned away.  The right
+    wall is not compared: its green was 1.7x as bright then as (0, 0.4, 0) of src/scene.rs:135 gives (as in
+    mis_40spp.jpg above); nor is anything near the two figure meshes the repository lacks."""
     regs = ref[1]["path1_linear"]
     hs = rt.HostScene("cornell_2light", 1.0, light_sampler=rt.SAMPLER_BLUE)
-    W = H = 160
+    W = H = 200
 
     def ratios(shader, spp):
         acc, _ = orc.OracleScene(hs.desc, 1).render(hs.camera, rt.default_params(W, H, spp, shader=shader, seed=3))
         lin = acc / spp
         return {name: region_mean(lin, r["box"]) / np.maximum(np.array(r["mean_rgb"]), 1e-4) for name, r in regs.items()}
 
-    rp = ratios(rt.SHADER_PATH, 200)
-    assert 0.93 < rp["left_wall_up"][0] < 1.2, rp["left_wall_up"]
-    assert (rp["back_white_top"] > 0.78).all() and (rp["back_white_top"] < 1.2).all(), rp["back_white_top"]
-    for name in ("ceiling_mid", "ceiling_front_left", "floor_front"):
-        assert (rp[name] > 0.65).all() and (rp[name] < 1.45).all(), (name, rp[name])
-    assert 0.5 < rp["right_wall_up"][1] < 0.68, rp["right_wall_up"]  # the documented exception, not a tolerance
-    rm = ratios(rt.SHADER_MIS, 48)
-    assert rm["left_wall_up"][0] < 0.8 and rm["floor_front"].mean() > 1.35, (rm["left_wall_up"], rm["floor_front"])
+    sp = channel_spreads(ratios(rt.SHADER_PATH, 500))
+    for (spread, med), (lo, hi) in zip(sp, [(1.0, 1.45), (0.7, 1.0), (1.0, 1.45)]):
+        assert spread < 1.55 and lo < med < hi, sp
+    sm = channel_spreads(ratios(rt.SHADER_MIS, 64))
+    assert all(spread > 1.6 for spread, _ in sm), sm

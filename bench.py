@@ -37,7 +37,7 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    import torch  # counting devices does not initialise the GPU
+    import torch  # (device_count() starts the HIP runtime in THIS process; harmless: the ranks are fresh child processes and this one never renders)
 
     have = torch.cuda.device_count()
     if have < n:

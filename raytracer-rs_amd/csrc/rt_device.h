@@ -315,7 +315,9 @@ __device__ __forceinline__ float u2f(unsigned int v) { return __uint_as_float(v)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Top-of-tree cache in LDS.  The boxes are the same in every visiting order, so they are kept once; only the
+// Top-of-tree cache in LDS.  The boxes are kept once, as order 0 stores them, i.e. as (min, max) pairs — the arrays of the
+// other orders hold an axis' pair as (max, min) where the octant's direction is negative, so a walk through this cache
+// must use the order-independent min / max box test (bvh_traverse does), never the presorted one of walk_range.  Only the
 // (link, miss) pairs are kept per order: [n_top x float4 (xmin,xmax,ymin,ymax)][n_top x float2 (zmin,zmax)]
 // [n_orders x n_top x int2 (link, miss)] = 24 + 8 * n_orders bytes per node.
 __host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (24u + 8u * (uint32_t)sc.n_orders); }

@@ -73,7 +73,4 @@ extern "C" {
                              n_nodes: *mut i32, n_top: *mut i32, n_orders: *mut i32) -> i32;   // host-only diagnostic
     pub fn rt_bvh_build_host_compact(tri_v: *const f32, n_tri: i32, ordered: i32, cnodes_out: *mut u32, q_params: *mut f32,
                                      n_nodes: *mut i32, n_orders: *mut i32) -> i32;   // host-only diagnostic
-    pub fn rt_bvh_build_host_walk(tri_v: *const f32, n_tri: i32, ordered: i32, max_hot: i32, cnodes_out: *mut u32, hot_box_out: *mut u32,
-                                  hot_links_out: *mut i32, q_params: *mut f32, n_cold: *mut i32, n_hot: *mut i32,
-                                  n_orders: *mut i32) -> i32;   // host-only diagnostic
 }

@@ -292,21 +292,6 @@ int32_t rt_bvh_build_host(const float *tri_v, int32_t n_tri, int32_t max_top, in
 int32_t rt_bvh_build_host_compact(const float *tri_v, int32_t n_tri, int32_t ordered, uint32_t *cnodes_out, float *q_params, int32_t *n_nodes,
                                   int32_t *n_orders);
 
-/* Host-only diagnostic: the layout the walk of heavy rays reads when rt_scene_create keeps the most visited nodes in a
- * table of their own (at most max_hot of them: the root, then always the largest child of a chosen node; the kernels
- * hold that table in LDS).  hot_box_out: 4 uint32 per hot node, x, y, z = lower plane | upper plane << 16 (quantised as
- * in rt_bvh_build_host_compact, NOT ordered by octant), w = leaf code (as above) or 0.  hot_links_out: per order and hot
- * node two int32 (first child, node to go on with after a miss or a leaf): >= 0 position in that order's cold array,
- * -1 walk finished, <= -2 hot node -2 - value.  cnodes_out: *n_orders arrays of *n_cold 16-byte records as in
- * rt_bvh_build_host_compact, holding only the subtrees below hot nodes, one after the other in visiting order; an inner
- * node's w may also be 0x40000000 | hot node (after a miss go on with that hot node), and where a leaf's successor is a
- * hot node the leaf is followed by a pass-on record, w = 0xC0000000 | hot node, that sends every ray there (a hot node
- * number >= *n_hot: walk finished; the arrays are padded with such records).  The walk starts at hot node 0 (at record
- * 0 when *n_hot is 0).
- * Output pointers may be NULL (sizes only): n_hot * 4, n_orders * n_hot * 2, n_orders * n_cold * 4 words. */
-int32_t rt_bvh_build_host_walk(const float *tri_v, int32_t n_tri, int32_t ordered, int32_t max_hot, uint32_t *cnodes_out, uint32_t *hot_box_out,
-                               int32_t *hot_links_out, float *q_params, int32_t *n_cold, int32_t *n_hot, int32_t *n_orders);
-
 #ifdef __cplusplus
 }
 #endif

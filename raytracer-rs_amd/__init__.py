@@ -389,9 +389,6 @@ def hip_lib() -> C.CDLL:
         lib.rt_bvh_build_host.restype = C.c_int32
         lib.rt_bvh_build_host_compact.argtypes = [c_float_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), c_float_p, c_int32_p, c_int32_p]
         lib.rt_bvh_build_host_compact.restype = C.c_int32
-        lib.rt_bvh_build_host_walk.argtypes = [c_float_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), c_int32_p,
-                                               c_float_p, c_int32_p, c_int32_p, c_int32_p]
-        lib.rt_bvh_build_host_walk.restype = C.c_int32
         _hip = lib
     return _hip
 
@@ -410,24 +407,6 @@ def bvh_build_host(tri_v: np.ndarray, max_top: int = 32, ordered: bool = True):
     tris = np.zeros((n, 12), np.float32)
     _check(lib.rt_bvh_build_host(_fp(tri_v), n, max_top, int(ordered), _fp(nodes), _fp(tris), C.byref(nn), C.byref(nt), C.byref(no)))
     return nodes, tris, nt.value
-
-
-def bvh_build_host_walk(tri_v: np.ndarray, max_hot: int, ordered: bool = True):
-    """rt_bvh_build_host_walk: (cold (n_orders, n_cold, 4) uint32, hot_box (n_hot, 4) uint32, hot_links (n_orders, n_hot, 2)
-    int32, q_params (6,) float32): the hot table the heavy rays' walk keeps in LDS and the cold subtrees below it."""
-    tri_v = np.ascontiguousarray(tri_v, np.float32).reshape(-1, 9)
-    n = tri_v.shape[0]
-    nc, nh, no = C.c_int32(), C.c_int32(), C.c_int32()
-    lib = hip_lib()
-    _check(lib.rt_bvh_build_host_walk(_fp(tri_v), n, int(ordered), int(max_hot), None, None, None, None, C.byref(nc), C.byref(nh), C.byref(no)))
-    cold = np.zeros((no.value, max(nc.value, 1), 4), np.uint32)
-    hot_box = np.zeros((max(nh.value, 1), 4), np.uint32)
-    hot_links = np.zeros((no.value, max(nh.value, 1), 2), np.int32)
-    q = np.zeros(6, np.float32)
-    _check(lib.rt_bvh_build_host_walk(_fp(tri_v), n, int(ordered), int(max_hot), cold.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                      hot_box.ctypes.data_as(C.POINTER(C.c_uint32)), hot_links.ctypes.data_as(c_int32_p), _fp(q),
-                                      C.byref(nc), C.byref(nh), C.byref(no)))
-    return cold[:, :nc.value], hot_box[:nh.value], hot_links[:, :nh.value], q
 
 
 def bvh_build_host_compact(tri_v: np.ndarray, ordered: bool = True):

@@ -97,8 +97,8 @@ struct rt_context {
 struct rt_scene {
     rt_context *ctx = nullptr;
     DevBuf<float4> nodes, tris, tri_nrm, sph, loose, loose_boxes;
-    DevBuf<uint4> cnodes, hot_box;
-    DevBuf<int2> sph_info, cyl_info, hot_links;
+    DevBuf<uint4> cnodes;
+    DevBuf<int2> sph_info, cyl_info;
     DevBuf<int32_t> tri_of_prim;
     DevBuf<float> cyl, ltris;
     DevBuf<rt_material> mats;
@@ -325,23 +325,6 @@ int32_t rt_bvh_build_host_compact(const float *tri_v, int32_t n_tri, int32_t ord
     if (n_orders) *n_orders = b.n_orders;
     if (q_params) for (int a = 0; a < 3; a++) { q_params[a] = b.q_lo[a]; q_params[3 + a] = b.q_scale[a]; }
     if (cnodes_out && !b.cnodes.empty()) std::memcpy(cnodes_out, b.cnodes.data(), b.cnodes.size() * sizeof(uint32_t));
-    return RT_OK;
-}
-
-int32_t rt_bvh_build_host_walk(const float *tri_v, int32_t n_tri, int32_t ordered, int32_t max_hot, uint32_t *cnodes_out, uint32_t *hot_box_out,
-                               int32_t *hot_links_out, float *q_params, int32_t *n_cold, int32_t *n_hot, int32_t *n_orders) {
-    if (n_tri < 0 || (n_tri > 0 && !tri_v) || max_hot < 0) return fail(RT_ERR_INVALID, "rt_bvh_build_host_walk: bad arguments");
-    std::vector<int32_t> prim((size_t)n_tri), mat((size_t)n_tri, 0);
-    for (int i = 0; i < n_tri; i++) prim[(size_t)i] = i;
-    BvhBuild b;
-    build_bvh(tri_v, prim.data(), mat.data(), n_tri, 0, ordered != 0, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &b, max_hot);
-    if (n_cold) *n_cold = b.n_cold;
-    if (n_hot) *n_hot = b.n_hot;
-    if (n_orders) *n_orders = b.n_orders;
-    if (q_params) for (int a = 0; a < 3; a++) { q_params[a] = b.q_lo[a]; q_params[3 + a] = b.q_scale[a]; }
-    if (cnodes_out && !b.cnodes.empty()) std::memcpy(cnodes_out, b.cnodes.data(), b.cnodes.size() * sizeof(uint32_t));
-    if (hot_box_out && !b.hot_box.empty()) std::memcpy(hot_box_out, b.hot_box.data(), b.hot_box.size() * sizeof(uint32_t));
-    if (hot_links_out && !b.hot_links.empty()) std::memcpy(hot_links_out, b.hot_links.data(), b.hot_links.size() * sizeof(int32_t));
     return RT_OK;
 }
 
@@ -610,12 +593,8 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         bvh.n_nodes = 2 * n_bvh - 1;
         bvh.n_orders = ordered ? 8 : 1;
         bvh.n_top = 0;
-        bvh.n_hot = 0;
-        bvh.n_cold = bvh.n_nodes;
     } else {
-        // nodes the walk of heavy rays keeps in LDS (RT_WALK_TOP, 0 = none): 16 + 8 * orders bytes each
-        const int max_hot = (int)std::min<uint32_t>(env_u32_allow_zero("RT_WALK_TOP", 256), 1024u);
-        build_bvh(bvh_v, bvh_prim, bvh_mat, n_bvh, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh, max_hot);
+        build_bvh(bvh_v, bvh_prim, bvh_mat, n_bvh, max_top, ordered, (int)env_u32("RT_BVH_LEAF", 2), (int)env_u32("RT_BVH_ARITY", 8), &bvh);
     }
     // the traversal addresses nodes and triangles through 32-bit byte offsets of a buffer descriptor
     if ((unsigned long long)bvh.n_nodes * (unsigned long long)bvh.n_orders * 32ull >= (1ull << 32) || (unsigned long long)d->n_tri * 48ull >= (1ull << 32)) {
@@ -670,15 +649,11 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
     } else {
         UP(s->nodes, bvh.nodes.data(), bvh.nodes.size() / 4, float4);
         UP(s->cnodes, bvh.cnodes.data(), bvh.cnodes.size() / 4, uint4);
-        UP(s->hot_box, bvh.hot_box.data(), bvh.hot_box.size() / 4, uint4);
-        UP(s->hot_links, bvh.hot_links.data(), bvh.hot_links.size() / 2, int2);
         UP(s->tris, bvh.tris.data(), bvh.tris.size() / 4, float4);
     }
     for (int a = 0; a < 3; a++) { s->dev.q_lo[a] = bvh.q_lo[a]; s->dev.q_scale[a] = bvh.q_scale[a]; }
     s->dev.cnodes = s->cnodes.p;
-    s->dev.n_cnodes = on_device ? n_cnodes : bvh.n_cold;
-    s->dev.hot_box = s->hot_box.p; s->dev.hot_links = s->hot_links.p;
-    s->dev.n_hot = bvh.n_hot;
+    s->dev.n_cnodes = on_device ? n_cnodes : bvh.n_nodes;
     {
         hipError_t e = s->tri_nrm.ensure((size_t)std::max(d->n_tri, 1));
         if (e == hipSuccess) {
@@ -824,7 +799,7 @@ int32_t rt_scene_destroy(rt_scene *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     s->loose_boxes.release();
-    s->nodes.release(); s->cnodes.release(); s->hot_box.release(); s->hot_links.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
+    s->nodes.release(); s->cnodes.release(); s->tris.release(); s->sph.release(); s->sph_info.release(); s->cyl.release(); s->cyl_info.release();
     s->tri_nrm.release(); s->mats.release(); s->lights.release(); s->ltris.release(); s->loose.release(); s->tri_of_prim.release();
     delete s;
     return RT_OK;

@@ -156,13 +156,9 @@ inline float int_bits(int v) {
 } // namespace
 
 void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, int max_arity,
-               BvhBuild *out, int max_hot) {
+               BvhBuild *out) {
     out->nodes.clear();
     out->tris.clear();
-    out->cnodes.clear();
-    out->hot_box.clear();
-    out->hot_links.clear();
-    out->n_hot = out->n_cold = 0;
     out->n_nodes = out->n_top = out->max_depth = 0;
     out->n_orders = 1;
     if (n_tri <= 0) return;
@@ -305,7 +301,7 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
         }
     }
 
-    // ---- the compact copy: per order, the hot table's links and the cold nodes in that order's depth-first sequence
+    // ---- the compact copy: per order, nodes in that order's depth-first sequence
     {
         const Box &rb = b.nodes[root].box;
         for (int a = 0; a < 3; a++) {
@@ -318,38 +314,12 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
             long long i = up ? (long long)std::ceil(q) + 1 : (long long)std::floor(q) - 1; // one step outwards: the kernel's float evaluation of q_lo + q * q_scale rounds
             return (uint32_t)std::min<long long>(65535, std::max<long long>(0, i));
         };
-        // the hot nodes: chosen like the first group of the numbering above, with a limit of their own
-        std::vector<int> hot(b.nodes.size(), -1);
-        int n_hot = 0;
-        if (max_hot > 0) {
-            auto cmp = [&](int x, int y) { return b.nodes[x].box.area() < b.nodes[y].box.area(); };
-            std::priority_queue<int, std::vector<int>, decltype(cmp)> q(cmp);
-            q.push(root);
-            while (!q.empty() && n_hot < max_hot) {
-                const int id = q.top();
-                q.pop();
-                hot[id] = n_hot++;
-                for (int c : kids[id]) q.push(c);
-            }
-        }
-        out->n_hot = n_hot;
-        out->hot_box.assign(4 * (size_t)n_hot, 0u);
-        out->hot_links.assign(2 * (size_t)n_hot * (size_t)out->n_orders, -1);
-        for (size_t id = 0; id < b.nodes.size(); id++) {
-            if (hot[id] < 0) continue;
-            const TmpNode &nd = b.nodes[id];
-            uint32_t *dst = &out->hot_box[4 * (size_t)hot[id]];
-            for (int a = 0; a < 3; a++) dst[a] = quant(nd.box.mn[a], a, false) | (quant(nd.box.mx[a], a, true) << 16);
-            dst[3] = kids[id].empty() ? (0x80000000u | (uint32_t)(nd.first * 8 + (nd.count - 1))) : 0u;
-        }
-        const uint32_t W_EXIT = 0x40000000u, W_PASS = 0xC0000000u, W_DONE = 0x3FFFFFFFu;
-        std::vector<std::vector<uint32_t>> per_order((size_t)out->n_orders);
+        out->cnodes.assign(4 * (size_t)nn * (size_t)out->n_orders, 0u);
         std::vector<int> dfs; // nodes of the current order in visiting sequence
         std::vector<int> subtree(b.nodes.size(), 0);
-        std::vector<int> pos(b.nodes.size(), -1); // position of a cold node in the current order's array
         for (int k = 0; k < out->n_orders; k++) {
             const int order = ordered ? k : 8;
-            std::vector<uint32_t> &arr = per_order[(size_t)k];
+            uint32_t *base = &out->cnodes[4 * (size_t)nn * (size_t)k];
             // iterative pre-order walk; subtree sizes from a post-order pass over the same sequence
             dfs.clear();
             std::vector<int> st{root};
@@ -367,62 +337,16 @@ void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, i
                 for (int c : kids[dfs[i]]) sz += subtree[c];
                 subtree[dfs[i]] = sz;
             }
-            // what follows pre-order index j in the walk, as a hot-table link (cold positions are known for j's node once it is laid out)
-            auto is_hot_at = [&](size_t j) { return j < dfs.size() && hot[dfs[j]] >= 0; };
-            size_t hang_first = 0, hang_end = 0; // pre-order range of the hanging subtree being laid out
-            uint32_t hang_pos = 0;                // its first record
             for (size_t i = 0; i < dfs.size(); i++) {
-                const int id = dfs[i];
-                if (hot[id] >= 0) continue;
-                if (i >= hang_end) { hang_first = i; hang_end = i + (size_t)subtree[id]; hang_pos = (uint32_t)(arr.size() / 4); }
-                pos[id] = (int)(arr.size() / 4);
-                const TmpNode &nd = b.nodes[id];
-                uint32_t rec[4];
+                const TmpNode &nd = b.nodes[dfs[i]];
+                uint32_t *dst = base + 4 * i;
                 for (int a = 0; a < 3; a++) {
                     const bool neg = ordered && ((k >> a) & 1);
                     const uint32_t lo = quant(nd.box.mn[a], a, false), hi = quant(nd.box.mx[a], a, true);
-                    rec[a] = neg ? (hi | (lo << 16)) : (lo | (hi << 16));
+                    dst[a] = neg ? (hi | (lo << 16)) : (lo | (hi << 16));
                 }
-                // does the walk leave the hanging subtree for a hot node (or end) after it?  else the next subtree's root follows it
-                // (after the last subtree the walk is over: the position behind it says so, as in the layout without hot nodes)
-                const bool exits = is_hot_at(hang_end);
-                const uint32_t exit_w = exits ? (W_EXIT | (uint32_t)hot[dfs[hang_end]]) : 0u;
-                if (kids[id].empty()) rec[3] = 0x80000000u | (uint32_t)(nd.first * 8 + (nd.count - 1));
-                else {
-                    const size_t j = i + (size_t)subtree[id]; // pre-order index the walk goes on with after a miss
-                    rec[3] = (j == hang_end && exits) ? exit_w : hang_pos + (uint32_t)(j - hang_first);
-                }
-                arr.insert(arr.end(), rec, rec + 4);
-                if (i + 1 == hang_end && exits) { // a leaf goes on with the record after it: one that sends every ray on
-                    const uint32_t pass[4] = {0u, 0u, 0u, W_PASS | (uint32_t)hot[dfs[hang_end]]};
-                    arr.insert(arr.end(), pass, pass + 4);
-                }
-            }
-            // links of the hot nodes in this order
-            auto enc = [&](size_t j) -> int32_t { // link to pre-order index j
-                if (j >= dfs.size()) return -1;
-                const int id = dfs[j];
-                return hot[id] >= 0 ? -2 - hot[id] : pos[id];
-            };
-            for (size_t i = 0; i < dfs.size(); i++) {
-                const int id = dfs[i];
-                if (hot[id] < 0) continue;
-                int32_t *dst = &out->hot_links[2 * ((size_t)k * (size_t)n_hot + (size_t)hot[id])];
-                dst[0] = kids[id].empty() ? -1 : enc(i + 1);
-                dst[1] = enc(i + (size_t)subtree[id]);
-            }
-        }
-        size_t n_cold = 1;
-        for (const auto &arr : per_order) n_cold = std::max(n_cold, arr.size() / 4);
-        out->n_cold = (int)n_cold;
-        out->cnodes.assign(4 * n_cold * (size_t)out->n_orders, 0u);
-        for (int k = 0; k < out->n_orders; k++) {
-            uint32_t *base = &out->cnodes[4 * n_cold * (size_t)k];
-            const auto &arr = per_order[(size_t)k];
-            std::copy(arr.begin(), arr.end(), base);
-            for (size_t i = arr.size() / 4; i < n_cold; i++) { // padding: sends every ray to the end of its walk
-                base[4 * i] = base[4 * i + 1] = base[4 * i + 2] = 0u;
-                base[4 * i + 3] = W_PASS | W_DONE;
+                if (kids[dfs[i]].empty()) dst[3] = 0x80000000u | (uint32_t)(nd.first * 8 + (nd.count - 1));
+                else dst[3] = (uint32_t)(i + (size_t)subtree[dfs[i]]);
             }
         }
     }

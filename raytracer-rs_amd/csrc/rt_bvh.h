@@ -27,23 +27,7 @@ struct BvhBuild {
     // x, y, z = entry plane | exit plane << 16, quantised to 16 bits over the root box (q_lo + q * q_scale; rounded
     // outwards by one step); w = inner node: index to go on with when the box is missed (n_nodes = walk finished);
     // leaf: 0x80000000 | first_triangle * 8 + count - 1 (a leaf is always followed by the next node).
-    //
-    // With max_hot > 0 the n_hot nodes rays meet most often (the root first, then always the largest not yet chosen child
-    // of a chosen node) are taken OUT of these arrays into a table the walk keeps in LDS (a CU's vector cache keeps
-    // nothing: thousands of rays, each after another cache line).  hot_box: 4 words per hot node, x, y, z = lower plane |
-    // upper plane << 16 (not ordered by octant: the lane swaps the halves along its negative axes), w = leaf: 0x80000000 |
-    // first_triangle * 8 + count - 1, inner node: 0.  hot_links: per order and hot node (first child, node to go on with
-    // after a miss or after a leaf), each >= 0: position in the order's cnodes array, -1: walk finished, <= -2: hot node
-    // -2 - value.  cnodes then holds, per order, only the subtrees hanging below hot nodes, each in depth-first order and
-    // one after the other in visiting order, n_cold records per order (the arrays are padded to a common length).  Where the
-    // walk leaves such a subtree for a hot node, an inner node on the subtree's last path has w = 0x40000000 | hot node
-    // instead of a position, and the subtree is followed by a pass-on record, w = 0xC0000000 | hot node, that sends every
-    // ray there whatever its box test says (a leaf goes on with the record after it); a hot node number >= n_hot ends the
-    // walk (the padding records).  n_hot = 0: one subtree, the whole tree (the layout described first).
     std::vector<uint32_t> cnodes;
-    std::vector<uint32_t> hot_box;
-    std::vector<int32_t> hot_links;
-    int n_hot = 0, n_cold = 0;
     float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
     int n_nodes = 0;
     int n_orders = 1;         // 8: one node array per direction octant (bit a set = component a negative); 1: direction-independent order
@@ -52,9 +36,8 @@ struct BvhBuild {
 };
 
 // tri_v: 9 floats per triangle; prim_id / mat per triangle.  max_top bounds n_top, max_leaf (1..4) the triangles per leaf,
-// max_arity the children per node after widening (2 = keep the binary tree), max_hot the nodes taken out of cnodes into
-// the hot table (0 = none).
+// max_arity the children per node after widening (2 = keep the binary tree).
 void build_bvh(const float *tri_v, const int32_t *prim_id, const int32_t *mat, int n_tri, int max_top, bool ordered, int max_leaf, int max_arity,
-               BvhBuild *out, int max_hot = 0);
+               BvhBuild *out);
 
 } // namespace rtd

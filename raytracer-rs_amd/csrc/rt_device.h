@@ -126,12 +126,6 @@ struct DevScene {
     const uint4 *cnodes;
     int32_t n_cnodes; // nodes per order in cnodes (the tree built on the GPU drops nodes there that it keeps in `nodes`)
     float q_lo[3], q_scale[3];
-    // ... of which the n_hot nodes rays meet most often are kept apart, for the walk to hold in LDS: hot_box[n_hot]
-    // (x, y, z = lower | upper << 16, w = leaf code or 0), hot_links[n_orders][n_hot] (first child, successor); cnodes
-    // then holds n_cnodes records per order (layout: rt_bvh.h).  n_hot = 0: cnodes holds the whole tree.
-    const uint4 *hot_box;
-    const int2 *hot_links;
-    int32_t n_hot;
     const float4 *nodes;
     const float4 *tris;
     const float4 *tri_nrm;      // per triangle record: unit geometric normal, material id (bits) in w
@@ -327,19 +321,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (link, miss) pairs are kept per order: [n_top x float4 (xmin,xmax,ymin,ymax)][n_top x float2 (zmin,zmax)]
 // [n_orders x n_top x int2 (link, miss)] = 24 + 8 * n_orders bytes per node.
 __host__ __device__ __forceinline__ uint32_t top_cache_bytes(const DevScene &sc) { return (uint32_t)sc.n_top * (24u + 8u * (uint32_t)sc.n_orders); }
-// LDS of a workgroup that walks heavy rays (walk_range): [hot_box: n_hot x 16 B][hot_links: n_orders x n_hot x 8 B], then,
-// 16-byte aligned, one WaveWalkLds per wave
-__host__ __device__ __forceinline__ uint32_t hot_table_bytes(const DevScene &sc) { return (uint32_t)sc.n_hot * (16u + 8u * (uint32_t)sc.n_orders); }
-__host__ __device__ __forceinline__ uint32_t walk_area_offset(const DevScene &sc) { return (hot_table_bytes(sc) + 15u) & ~15u; }
-// every thread of the workgroup must call it; ends with a barrier
-template <int BLOCK_THREADS>
-__device__ __forceinline__ void fill_hot_table(const DevScene &sc, uint4 *lds) {
-    const uint32_t n_box = (uint32_t)sc.n_hot, n_link = (uint32_t)sc.n_hot * (uint32_t)sc.n_orders;
-    int2 *links = reinterpret_cast<int2 *>(lds + n_box);
-    for (uint32_t j = threadIdx.x; j < n_box; j += BLOCK_THREADS) lds[j] = sc.hot_box[j];
-    for (uint32_t j = threadIdx.x; j < n_link; j += BLOCK_THREADS) links[j] = sc.hot_links[j];
-    __syncthreads();
-}
+// ... followed, 16-byte aligned, by one WaveWalkLds per wave of the workgroup
+__host__ __device__ __forceinline__ uint32_t wave_area_offset(const DevScene &sc, bool use_lds) { return use_lds ? ((top_cache_bytes(sc) + 15u) & ~15u) : 0u; }
 // every thread of the workgroup must call it
 template <int BLOCK_THREADS>
 __device__ __forceinline__ void fill_top_cache(const DevScene &sc, float4 *lds_nodes) {
@@ -516,19 +499,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 //                           void done(uint32_t k, F3 o, F3 d, const TriHit &h)   closest hit: h.prim (-1 = none), h.t;
 //                                                                                 occlusion query: h.tri >= 0 = occluded
 // Every lane of the wave must call walk_range; `wl` is the calling wave's own area.
-//
-// A lane's `node`: >= 0 position in its order's cnodes array, -1 no node (walk over), <= -2 hot node -2 - node, read from
-// the workgroup's LDS copy of the hot table (`hot_lds`, filled by fill_hot_table).  One pass of the loop first takes the
-// lanes at hot nodes through the table until they stand at cold nodes, then every lane at a cold node one step (a fetch
-// from memory).
 template <bool ANY_HIT, bool COUNT, class Client>
-__device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, const uint4 *hot_lds, Client &client, uint32_t first, uint32_t total,
+__device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, Client &client, uint32_t first, uint32_t total,
                                            float t_min, float t_max, uint32_t *n_nodes, uint32_t *n_tris) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t NONE = 0xFFFFFFFFu;
     const __amdgpu_buffer_rsrc_t node_r = make_rsrc(sc.cnodes, (uint32_t)sc.n_cnodes * (uint32_t)sc.n_orders * 16u);
-    const uint32_t n_hot = uni((uint32_t)sc.n_hot), n_cold = uni((uint32_t)sc.n_cnodes);
-    const int2 *hot_links_lds = reinterpret_cast<const int2 *>(hot_lds + n_hot);
     const __amdgpu_buffer_rsrc_t tri_r = make_rsrc(sc.tris, (uint32_t)sc.n_tri * 48u);
     const unsigned long long key0 = ANY_HIT ? 1ull : (((unsigned long long)float_order_key(t_max) << 32) | 0x80000000ull); // (t_max, prim -1)
     const bool presorted = sc.n_orders == 8;
@@ -538,7 +514,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
     // per-ray state of the lane
     uint32_t my_k = NONE;
     f32x2 ix2 = {0.0f, 0.0f}, iy2 = ix2, iz2 = ix2, ox2 = ix2, oy2 = ix2, oz2 = ix2;
-    uint32_t g_base = 0, oct = 0;
+    uint32_t g_base = 0;
     float cull_t = t_max;
     int node = -1;
     bool pushed = false;
@@ -553,7 +529,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
     for (;;) {
         // Lanes without work are looked after when enough of them have gathered: their queued leaves are tested at once
         // (even fewer than 64), which makes their results final, and they take new rays.
-        const uint32_t n_walk = uni((uint32_t)__popcll(__ballot(node != -1)));
+        const uint32_t n_walk = uni((uint32_t)__popcll(__ballot(node >= 0)));
         const bool starving = next < total && n_walk + refill <= 64u;
         if (n_walk != 0u && count < batch && !starving) {
             // One step of the walk for every lane that has a node; leaves are queued, not tested.  The walk waits for one
@@ -575,15 +551,10 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 }
                 const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
                 const bool is_leaf = (int)nd.w < 0;
-                const bool pass_on = nd.w >= 0xC0000000u; // no node: the record after a cold subtree whose successor is a hot node
-                *leaf = (inside && is_leaf && !pass_on) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
+                *leaf = (inside && is_leaf) ? (int)(nd.w & 0x7FFFFFFFu) : -1;
                 // depth-first order: the first child of an inner node and the successor of a leaf are the next node
-                const uint32_t nxt = pass_on ? (nd.w & 0x7FFFFFFFu) : (inside || is_leaf) ? (uint32_t)at + 1u : nd.w;
-                if (nxt & 0x40000000u) { // the walk leaves the cold subtree: for a hot node, or for good
-                    const uint32_t h = nxt & 0x3FFFFFFFu;
-                    return h < n_hot ? -2 - (int)h : -1;
-                }
-                return nxt < n_cold ? (int)nxt : -1;
+                const uint32_t nxt = (inside || is_leaf) ? (uint32_t)at + 1u : nd.w;
+                return nxt < (uint32_t)sc.n_cnodes ? (int)nxt : -1;
             };
             auto push_leaves = [&](int leaf) { // every lane of the wave calls it
                 const unsigned long long m = __ballot(leaf >= 0);
@@ -597,41 +568,6 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                     count = uni(count + (uint32_t)__popcll(m));
                 }
             };
-            // Lanes at hot nodes first: they step through the LDS table — two LDS reads and a box test per step, no memory
-            // round trip — until every one of them stands at a cold node or has finished (or the leaf queue has a batch to
-            // test: a hot step queues up to 64 leaves).  New rays start at the root, so a burst follows every refill.
-            if (n_hot != 0u) {
-                while (count < batch && __ballot(node <= -2) != 0ull) {
-                    int leaf_h = -1;
-                    if (node <= -2) {
-                        const uint32_t h = (uint32_t)(-2 - node);
-                        const uint4 hb = hot_lds[h];
-                        const int2 hl = hot_links_lds[oct * n_hot + h];
-                        if (COUNT) (*n_nodes) += 0x10000u; // (hot steps in the upper half of the counter)
-                        // the table's boxes are (lower, upper): along the lane's negative axes the halves change places
-                        const uint32_t bx = __builtin_amdgcn_alignbit(hb.x, hb.x, (oct & 1u) << 4), by = __builtin_amdgcn_alignbit(hb.y, hb.y, (oct & 2u) << 3),
-                                       bz = __builtin_amdgcn_alignbit(hb.z, hb.z, (oct & 4u) << 2);
-                        const f32x2 tx = __builtin_elementwise_fma(f32x2{(float)(bx & 0xFFFFu), (float)(bx >> 16)}, ix2, ox2);
-                        const f32x2 ty = __builtin_elementwise_fma(f32x2{(float)(by & 0xFFFFu), (float)(by >> 16)}, iy2, oy2);
-                        const f32x2 tz = __builtin_elementwise_fma(f32x2{(float)(bz & 0xFFFFu), (float)(bz >> 16)}, iz2, oz2);
-                        float tn, tf;
-                        if (presorted) {
-                            tn = max3_raw(tx.x, ty.x, max_raw(tz.x, t_min_v));
-                            tf = min3_raw(tx.y, ty.y, min_raw(tz.y, cull_t));
-                        } else {
-                            tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), t_min));
-                            tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), cull_t));
-                        }
-                        const bool inside = tn <= __builtin_fmaf(tf, 1.00001f, 1e-7f);
-                        const bool is_leaf = (int)hb.w < 0;
-                        leaf_h = (inside && is_leaf) ? (int)(hb.w & 0x7FFFFFFFu) : -1;
-                        node = (inside && !is_leaf) ? hl.x : hl.y;
-                    }
-                    push_leaves(leaf_h);
-                }
-            }
-            // ... then one step for the lanes at cold nodes (at most 63 + 64 entries are queued at this point, the step adds at
-            // most 128: the ring holds 256)
             int leaf = -1, leaf1 = -1;
             if (node >= 0) {
                 const int at = node;
@@ -642,7 +578,7 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 if (pairs && node == at + 1) node = test_node(nd1, at + 1, &leaf1);
             }
             push_leaves(leaf);
-            if (pairs) push_leaves(leaf1);
+            if (pairs) push_leaves(leaf1); // at most 63 + 64 + 64 entries: the ring holds 256
             continue;
         }
         if (count > 0u) {
@@ -690,9 +626,9 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
         }
         // Retire and refill.  Looked at only here — after a batch of tests, or when nothing is left to do — not at every
         // step: a lane's result becomes final when its walk is over and the queue has moved past its last leaf.
-        const bool fin = my_k != NONE && node == -1 && (!pushed || (int32_t)(head - last_pos) > 0);
+        const bool fin = my_k != NONE && node < 0 && (!pushed || (int32_t)(head - last_pos) > 0);
         const uint32_t n_fin = uni((uint32_t)__popcll(__ballot(fin))), n_idle = uni((uint32_t)__popcll(__ballot(my_k == NONE)));
-        const bool drained = count == 0u && __ballot(node != -1) == 0ull;
+        const bool drained = count == 0u && __ballot(node >= 0) == 0ull;
         if (drained || (next < total && n_fin + n_idle >= refill)) {
             if (fin) {
                 const unsigned long long r = wl.best[lane];
@@ -728,13 +664,12 @@ __device__ __forceinline__ void walk_range(const DevScene &sc, WaveWalkLds &wl, 
                 // the octant is taken from the SIGN BITS (a component of -0 has a reciprocal of -inf): it decides which of a
                 // node's two planes per axis is the entry plane, and must agree with the sign of the reciprocal
                 const uint32_t octant = presorted ? ((__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2)) : 0u;
-                oct = octant;
-                g_base = octant * n_cold * 16u;
+                g_base = octant * (uint32_t)sc.n_cnodes * 16u;
                 wl.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
                 wl.ray_b[lane] = make_float2(d.y, d.z);
                 wl.best[lane] = (ANY_HIT && !walk) ? 0ull : k_init;
                 cull_t = ANY_HIT ? t_max : init.t;
-                node = (walk && sc.n_cnodes > 0) ? (n_hot != 0u ? -2 : 0) : -1; // the root is the first hot node
+                node = (walk && sc.n_cnodes > 0) ? 0 : -1;
                 pushed = false;
             }
             next = uni(next + min((uint32_t)__popcll(free_m), remaining));

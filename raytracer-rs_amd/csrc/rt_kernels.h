@@ -69,7 +69,6 @@ struct CtlHead {
     // work-counting launches only: closest-hit rays / waves by floor(log2(visited nodes)) + 1 (bucket 0 = none), and the
     // sum over waves of the largest count among their lanes (the walk length the wave actually pays for)
     unsigned long long hist_ray[16], hist_wave[16], wave_steps, wave_tri_iters;
-    unsigned long long hot_steps; // steps of heavy rays' walks answered by the LDS-resident hot table (work counting)
 };
 
 struct Ctl {

@@ -353,15 +353,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, RenderConst rc, C
         if (wg_first >= n_seg) return;
         const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
         const uint32_t total = first < n_seg ? min(heavy_span, n_seg - first) : 0u;
-        uint4 *hot_lds = reinterpret_cast<uint4 *>(lds_nodes);
-        if (sc.n_hot > 0) fill_hot_table<BLOCK>(sc, hot_lds);
-        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + walk_area_offset(sc));
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
         ExtendClient client{sc, rc, in, hit, seg * seg_capacity};
         uint32_t nn = 0, nt = 0;
-        walk_range<false, COUNT>(sc, areas[wave], hot_lds, client, first, total, rc.t_min, rc.t_max, &nn, &nt);
+        walk_range<false, COUNT>(sc, areas[wave], client, first, total, rc.t_min, rc.t_max, &nn, &nt);
         if (COUNT) {
-            atomicAdd(&ctl->h.hot_steps, (unsigned long long)(nn >> 16));
-            nn &= 0xFFFFu;
             atomicAdd(&ctl->h.nodes, (unsigned long long)nn);
             atomicAdd(&ctl->h.tris, (unsigned long long)nt);
             atomicAdd(&ctl->h.scanned, (unsigned long long)client.scanned);
@@ -967,15 +963,11 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(DevScene sc, RenderConst rc, C
         if (wg_first >= n) return;
         const uint32_t wave = threadIdx.x >> 6, first = wg_first + wave * heavy_span;
         const uint32_t total = first < n ? min(heavy_span, n - first) : 0u;
-        uint4 *hot_lds = reinterpret_cast<uint4 *>(lds_nodes);
-        if (sc.n_hot > 0) fill_hot_table<BLOCK>(sc, hot_lds);
-        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + walk_area_offset(sc));
+        WaveWalkLds *areas = reinterpret_cast<WaveWalkLds *>(reinterpret_cast<char *>(lds_nodes) + wave_area_offset(sc, USE_LDS));
         ShadowClient client{sc, rc, sh, planes, n_pixels, seg * shadow_seg_capacity};
         uint32_t nn = 0, nt = 0;
-        walk_range<true, COUNT>(sc, areas[wave], hot_lds, client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
+        walk_range<true, COUNT>(sc, areas[wave], client, first, total, rc.t_min, 1.0f - rc.t_min, &nn, &nt);
         if (COUNT) {
-            atomicAdd(&ctl->h.hot_steps, (unsigned long long)(nn >> 16));
-            nn &= 0xFFFFu;
             atomicAdd(&ctl->h.nodes_sh, (unsigned long long)nn);
             atomicAdd(&ctl->h.tris_sh, (unsigned long long)nt);
             atomicAdd(&ctl->h.scanned, (unsigned long long)client.scanned);
@@ -1153,8 +1145,7 @@ __global__ __launch_bounds__(BLOCK) void k_accum_add(float *dst, const float *sr
 static inline uint32_t nblocks(uint32_t n) { return (n + BLOCK - 1) / BLOCK; }
 // dynamic LDS of the traversal kernels: the top of the tree (when cached) + one queue area per wave
 static inline size_t lds_bytes(const DevScene &sc, bool use_lds) {
-    // light workgroups: the top of the 32-byte-node tree; heavy workgroups: the hot table + one queue area per wave
-    size_t need = std::max<size_t>(use_lds ? top_cache_bytes(sc) : 0u, walk_area_offset(sc) + (BLOCK / 64) * sizeof(WaveWalkLds));
+    size_t need = wave_area_offset(sc, use_lds) + (BLOCK / 64) * sizeof(WaveWalkLds);
     // experiment: a larger request lowers the number of resident workgroups per CU
     if (const char *v = std::getenv("RT_WALK_LDS_KB")) need = std::max(need, (size_t)std::atoi(v) * 1024u);
     return need;

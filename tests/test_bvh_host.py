@@ -20,18 +20,6 @@ def soup(n, seed, flat=False):
     return v.astype(F).reshape(n, 9)
 
 
-def room(n, seed):
-    """A soup inside a closed box of 12 large triangles facing inwards: boxes that span the whole root box along two axes,
-    leaves high up in the tree."""
-    lo, hi = -15.0, 15.0
-    c = [(lo, lo, lo), (hi, lo, lo), (hi, hi, lo), (lo, hi, lo), (lo, lo, hi), (hi, lo, hi), (hi, hi, hi), (lo, hi, hi)]
-    quads = [(0, 1, 2, 3), (5, 4, 7, 6), (4, 0, 3, 7), (1, 5, 6, 2), (4, 5, 1, 0), (3, 2, 6, 7)]
-    walls = []
-    for a, b, cc, d in quads:
-        walls += [c[a] + c[b] + c[cc], c[a] + c[cc] + c[d]]
-    return np.concatenate([soup(n, seed), np.array(walls, F)]).astype(F)
-
-
 def links(nodes):
     return nodes[..., 6].view(np.int32), nodes[..., 7].view(np.int32)
 
@@ -298,116 +286,3 @@ def test_compact_nodes_structure_and_walk(rt, n, ordered):
         octant = int(np.signbit(d[0])) | (int(np.signbit(d[1])) << 1) | (int(np.signbit(d[2])) << 2) if ordered else 0
         got = walk_compact(cn[octant], q, tris, octant, o, d, F(1e-3), F(1e7), presorted=ordered)
         assert got[:2] == want, (o, d)
-
-
-def walk_hot_cold(cold, hot_box, hot_links, q, tris, octant, o, d, t_min, t_max, presorted):
-    """walk_range's two kinds of step (rt_device.h) in numpy: hot nodes from the table (boxes as (lower, upper), swapped by
-    the ray along its negative axes; explicit first child and successor), cold nodes as in walk_compact, and the exits
-    from a cold subtree (w = 0x40000000 | hot node).  Returns (t, primitive, cold visits, hot visits)."""
-    n_cold, n_hot = cold.shape[0], hot_box.shape[0]
-    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        inv = (F(1.0) / d).astype(F)
-        a = (q[3:6] * inv).astype(F)
-        b = ((q[0:3] - o) * inv).astype(F)
-        best_t, best_p = F(t_max), -1
-        node = -2 if n_hot else 0
-        n_c = n_h = 0
-
-        def box(w3):
-            e = ((w3 & 0xFFFF).astype(F) * a + b).astype(F)
-            x = ((w3 >> 16).astype(F) * a + b).astype(F)
-            if presorted:
-                tn, tf = np.fmax(np.fmax.reduce(e), F(t_min)), np.fmin(np.fmin.reduce(x), best_t)
-            else:
-                tn, tf = np.fmax(np.fmax.reduce(np.fmin(e, x)), F(t_min)), np.fmin(np.fmin.reduce(np.fmax(e, x)), best_t)
-            return bool(tn <= F(tf * F(1.00001) + F(1e-7)))
-
-        def test_leaf(code):
-            nonlocal best_t, best_p
-            for k in range(code >> 3, (code >> 3) + (code & 7) + 1):
-                t = tri_hit(tris[k, 0:3], tris[k, 4:7], tris[k, 8:11], o, d, t_min, t_max)
-                if t is not None:
-                    p = int(tris[k, 3:4].view(np.int32)[0])
-                    if t < best_t or (t == best_t and p > best_p):
-                        best_t, best_p = t, p
-
-        while node != -1:
-            assert n_c + n_h <= 4 * (n_cold + n_hot) + 4, "the walk does not end"
-            if node <= -2:
-                h = -2 - node
-                assert h < n_hot
-                n_h += 1
-                w = hot_box[h].copy()
-                if presorted:
-                    for ax in range(3):
-                        if (octant >> ax) & 1:
-                            w[ax] = ((int(w[ax]) >> 16) | (int(w[ax]) << 16)) & 0xFFFFFFFF
-                inside = box(w[:3])
-                leaf = bool(w[3] >> 31)
-                if inside and leaf:
-                    test_leaf(int(w[3] & 0x7FFFFFFF))
-                node = int(hot_links[h, 0] if (inside and not leaf) else hot_links[h, 1])
-            else:
-                n_c += 1
-                w = cold[node]
-                inside = box(w[:3])
-                leaf = bool(w[3] >> 31)
-                pass_on = int(w[3]) >= 0xC0000000
-                if inside and leaf and not pass_on:
-                    test_leaf(int(w[3] & 0x7FFFFFFF))
-                nxt = int(w[3]) & 0x7FFFFFFF if pass_on else node + 1 if (inside or leaf) else int(w[3])
-                if nxt & 0x40000000:
-                    h = nxt & 0x3FFFFFFF
-                    node = -2 - h if h < n_hot else -1
-                else:
-                    node = nxt if nxt < n_cold else -1
-    return best_t, best_p, n_c, n_h
-
-
-@pytest.mark.parametrize("n,ordered,max_hot", [(1, True, 4), (3, False, 2), (40, True, 1), (200, True, 16), (200, False, 64), (200, True, 10_000),
-                                               (1200, True, 128), (1200, True, 7), (-300, True, 24), (-300, False, 24), (-900, True, 200)])
-def test_hot_table_and_cold_subtrees(rt, n, ordered, max_hot):
-    """The layout with the most visited nodes in a table of their own: every triangle sits in exactly one leaf (hot or
-    cold) of every order, all orders have the same hot nodes, and the walk finds the brute-force closest hit."""
-    tri_v = room(-n, max_hot - 3 * n) if n < 0 else soup(n, 3 * n + max_hot, flat=(n == 200))  # n < 0: a soup of -n triangles in a closed box
-    n = tri_v.shape[0]
-    cold, hot_box, hot_links, q = rt.bvh_build_host_walk(tri_v, max_hot, ordered=ordered)
-    cn, q0 = rt.bvh_build_host_compact(tri_v, ordered=ordered)
-    _, tris, _ = rt.bvh_build_host(tri_v, max_top=0, ordered=ordered)
-    n_orders, n_cold, n_hot = cold.shape[0], cold.shape[1], hot_box.shape[0]
-    assert n_orders == (8 if ordered else 1) and np.array_equal(q, q0)
-    assert 1 <= n_hot <= min(max_hot, cn.shape[1])
-    hot_leaves = [int(w & 0x7FFFFFFF) for w in hot_box[:, 3] if w >> 31]
-    for k in range(n_orders):
-        c = cold[k]
-        real = c[:, 3] < 0xC0000000  # not a pass-on record / padding
-        assert int(real.sum()) + n_hot == cn.shape[1]  # every node of the tree is hot or cold
-        leaf = real & (c[:, 3] >> 31).astype(bool)
-        seen = []
-        for code in [int(w & 0x7FFFFFFF) for w in c[leaf, 3]] + hot_leaves:
-            seen += list(range(code >> 3, (code >> 3) + (code & 7) + 1))
-        assert sorted(seen) == list(range(n))
-        # links stay in range; exits name hot nodes
-        lk = hot_links[k]
-        assert ((lk >= -2 - (n_hot - 1)) & (lk < n_cold)).all()
-        inner = real & ~leaf
-        w = c[inner, 3]
-        ex = (w & 0x40000000).astype(bool)
-        assert ((w[ex] & 0x3FFFFFFF) < n_hot).all() and (w[~ex] <= n_cold).all()
-    rng = np.random.default_rng(n + max_hot)
-    hot_seen = 0
-    for _ in range(60 if n <= 200 else 25):
-        o = rng.uniform(-14, 14, 3).astype(F)
-        d = rng.normal(size=3).astype(F)
-        if rng.random() < 0.2:
-            d[rng.integers(3)] = F(0.0) * (F(-1.0) if rng.random() < 0.5 else F(1.0))
-        want = brute(tris, o, d, F(1e-3), F(1e7))
-        octant = int(np.signbit(d[0])) | (int(np.signbit(d[1])) << 1) | (int(np.signbit(d[2])) << 2) if ordered else 0
-        got = walk_hot_cold(cold[octant], hot_box, hot_links[octant], q, tris, octant, o, d, F(1e-3), F(1e7), presorted=ordered)
-        assert got[:2] == want, (o, d)
-        # the same nodes are visited as in the layout without a table (the order of the walk is the same)
-        ref = walk_compact(cn[octant], q, tris, octant, o, d, F(1e-3), F(1e7), presorted=ordered)
-        real_visits = got[2] + got[3]
-        assert ref[2] <= real_visits <= ref[2] + got[3] + 1  # + the pass-on records met after a leaf
-        hot_seen += got[3]
-    assert hot_seen > 0

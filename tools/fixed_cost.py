@@ -8,7 +8,7 @@ hs = rt.HostScene("utah", w / h)
 ctx = rt.Context(0)
 ds = rt.DeviceScene(ctx, hs.desc)
 acc = torch.zeros(h, w, 3, device="cuda")
-for spp in (1, 2, 4, 8, 16, 32):
+for spp in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     p = rt.default_params(w, h, spp)
     best = 1e9
     for rep in range(4):

@@ -18,4 +18,6 @@ bash tools/pmc_workload.sh rel_c3 "--workload c3_utah" > $out/pmc_c3.log 2>&1 ||
 bash tools/pmc_workload.sh rel_c4 "--workload c4_miku --spp 64" > $out/pmc_c4.log 2>&1 || exit 1
 bash tools/pmc_workload.sh rel_c5 "--workload c5_composite --spp 8" > $out/pmc_c5.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/bvh_build_times.py utah miku composite > $out/bvh_build_times.txt 2>/dev/null || exit 1
+
+timeout -k 10 200 python3 tools/fixed_cost.py > $out/fixed_cost.txt 2>/dev/null || exit 1
 echo release done

@@ -108,6 +108,9 @@ struct rt_scene {
     int n_prims = 0;
     int n_point_lights = 0, n_disk_lights = 0;
     rt_scene_info info{};
+    // What the end of a render call has cost on this scene, per shader, in ms per bounce still to go: by the tail kernel
+    // (one thread per path) and by the staged kernels at the population where the tail takes over; < 0 = not measured yet.
+    double tail_ms_per_bounce[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, staged_ms_per_bounce[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 };
 
 // Device memory one render call works in: the two path-node queues, hit records, the two shadow-ray queues, the tiled
@@ -894,6 +897,21 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         // paths left when the staged iterations hand over to k_tail (RT_TAIL, 0 = never); not for the Whitted shader
         // (several shadow rays per node) nor for work-counting calls
         const uint32_t tail_limit = (p->shader == RT_SHADER_WHITTED || count_work) ? 0u : env_u32_allow_zero("RT_TAIL", 1u << 18);
+        // Whether the tail kernel pays depends on the scene: a thread that walks big meshes alone does it at a few lanes
+        // per wave, and where such paths dominate the staged kernels finish the call sooner (Miku at 128 spp: 270 ms with the
+        // tail, 254 without; Cornell at 16 spp: 10.1 with, 13.4 without).  So it is measured: the first call on a scene uses
+        // the tail and notes what it cost per bounce still to go, and what the last staged iteration before it cost; later
+        // calls use the tail only where it was the cheaper one (RT_TAIL_ADAPT=0: always).  Results do not depend on it.
+        const bool tail_adapt = env_u32_allow_zero("RT_TAIL_ADAPT", 1) != 0;
+        const int tail_key = p->shader & 7;
+        bool tail_pays = true;
+        if (tail_adapt && s->tail_ms_per_bounce[tail_key] >= 0.0 && s->staged_ms_per_bounce[tail_key] >= 0.0)
+            tail_pays = s->tail_ms_per_bounce[tail_key] < s->staged_ms_per_bounce[tail_key];
+        auto t_readback = std::chrono::steady_clock::now(); // wall clock of the previous read-back
+        double last_staged_ms = -1.0;                        // duration of the last staged iteration without new camera rays
+        int drain_iters = 0;                                 // iterations since the last camera ray was added
+        int tail_bounces_left = 0;                           // > 0: the previous iteration was the tail kernel's first launch
+        bool prev_staged_drain = false;
         for (;;) {
             if (shadow_pending && overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->shadow_done, 0)); // k_plan rewrites the counts k_shadow reads
             shadow_pending = false;
@@ -903,6 +921,18 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
             if (c.overflow) return loop_fail(RT_ERR_NOMEM, overflow_msg);
+            {
+                const auto now = std::chrono::steady_clock::now();
+                const double ms = std::chrono::duration<double, std::milli>(now - t_readback).count();
+                t_readback = now;
+                if (prev_staged_drain) last_staged_ms = ms;
+                if (tail_bounces_left > 0) { // the iteration that just ended was the tail kernel
+                    s->tail_ms_per_bounce[tail_key] = ms / tail_bounces_left;
+                    if (last_staged_ms >= 0.0) s->staged_ms_per_bounce[tail_key] = last_staged_ms;
+                    tail_bounces_left = 0;
+                }
+                prev_staged_drain = false;
+            }
             if (dump_iter) // development aid: the population and the wall clock at every iteration
                 std::fprintf(stderr, "[rt] %8.3f ms: %u nodes carried in, %u camera rays to add, shadow rays <= %u + %u per segment\n",
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c.n_alive, c.n_new, c.max_sh_light,
@@ -936,8 +966,12 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             const uint32_t fresh = ((new_blocks + RT_NSEG_HALF - 1) / RT_NSEG_HALF) * RT_RAYGEN_PER_WG;
             const uint32_t light_threads = std::min(seg_capacity, c.max_in_light + fresh);
             const uint32_t heavy_threads = s->dev.n_heavy ? std::min(seg_capacity, c.max_in_heavy + fresh) : c.max_in_heavy;
-            if (tail_limit && c.n_new == 0 && c.cursor == c.total && c.n_alive <= tail_limit) {
+            const bool draining = c.n_new == 0 && c.cursor == c.total;
+            if (draining) drain_iters++;
+            if (tail_limit && tail_pays && draining && c.n_alive <= tail_limit) {
                 // the last few paths: one launch follows each of them to its end (see k_tail)
+                if (last_staged_ms >= 0.0 && tail_bounces_left == 0 && s->tail_ms_per_bounce[tail_key] < 0.0)
+                    tail_bounces_left = std::max(1, p->max_depth + 1 - drain_iters); // (an upper bound: the youngest path left was born drain_iters ago)
                 timer.begin(0);
                 DevScene dev_tail = s->dev;
                 if (carry_in) st.nodes_carrying += c.n_alive;
@@ -953,6 +987,7 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
                 scur ^= 1;
                 continue;
             }
+            prev_staged_drain = draining && c.n_alive <= 4u * std::max(tail_limit, 1u);
             timer.begin(0);
             launch_extend(cfg, s->dev, rcst, pool.ctl, in, pool.hit, light_threads, heavy_threads, count_work);
             timer.end();

@@ -154,6 +154,7 @@ def test_tile_shards_compose_to_the_whole_frame(rt, gpu_ctx):
 
 
 def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, monkeypatch):
+    monkeypatch.setenv("RT_TAIL_ADAPT", "0")  # iteration counts of two calls on one scene are compared
     hs = rt.HostScene("head", 1.0)
     ds = rt.DeviceScene(gpu_ctx, hs.desc)
     p = rt.default_params(96, 96, 8)
@@ -168,7 +169,7 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
 
 KNOBS = [{"RT_CARRY": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "2", "RT_TAIL": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "0"}, {"RT_CARRY": "1", "RT_INLINE_SHADOW": "1", "RT_QUEUE_TARGET": "30000"}, {"RT_DEFERRED": "0"}, {"RT_WALK_SPAN": "1"}, {"RT_WALK_SPAN": "16", "RT_QUEUE_TARGET": "100000"}, {"RT_INLINE_SHADOW": "0"}, {"RT_INLINE_SHADOW": "2"}, {"RT_INLINE_SHADOW": "2", "RT_LOOSE_MAX": "0"}, {"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
          {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"},
-         {"RT_LOOSE_BOXES": "0"}, {"RT_LOOSE_BOXES": "0", "RT_INLINE_SHADOW": "0", "RT_CARRY": "0"}]
+         {"RT_LOOSE_BOXES": "0"}, {"RT_LOOSE_BOXES": "0", "RT_INLINE_SHADOW": "0", "RT_CARRY": "0"}, {"RT_TAIL_ADAPT": "0"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
@@ -211,6 +212,7 @@ def test_scan_of_loose_triangles_matches_the_walk(rt, orc, gpu_ctx, monkeypatch,
 def test_roulette_keeps_the_mean_and_shortens_paths(rt, gpu_ctx, monkeypatch):
     """RT_FLAG_RUSSIAN_ROULETTE: same expectation as the reference's estimator (which only stops at depth 40,
     src/shader.rs:94-96) with a fraction of the rays; identical with and without the tail kernel."""
+    monkeypatch.setenv("RT_TAIL_ADAPT", "0")  # iteration counts are compared: the tail kernel in both calls, whatever the first one cost
     hs = rt.HostScene("head", 1.0)
     ds = rt.DeviceScene(gpu_ctx, hs.desc)
     spp = 256
@@ -256,6 +258,7 @@ def test_light_carried_along_the_path_gives_the_same_image(rt, gpu_ctx, monkeypa
 def test_tail_kernel_traces_the_same_rays(rt, gpu_ctx, monkeypatch):
     """The last paths of a call are followed to their end by one kernel launch instead of one wavefront iteration per
     bounce (RT_TAIL = population at which that starts, 0 = never): same rays, same image, fewer iterations."""
+    monkeypatch.setenv("RT_TAIL_ADAPT", "0")  # the tail kernel whenever RT_TAIL says so, whatever it cost in the call before
     hs = rt.HostScene("utah", 16 / 9)  # Microfacet teapot: second children wait on the tail kernel's stack
     ds = rt.DeviceScene(gpu_ctx, hs.desc)
     p = rt.default_params(160, 90, 8)
@@ -919,3 +922,20 @@ def test_device_built_bvh_thinned_in_any_way_gives_the_same_image(rt, orc, gpu_c
         assert_radiance_close(da, ca)
         host.close()
         dev.close()
+
+
+def test_adaptive_tail_choice_does_not_change_results(rt, gpu_ctx, monkeypatch):
+    """The first call on a scene ends with the tail kernel and notes what that cost against the staged kernels; later calls
+    use whichever was cheaper (on the mesh-dominated frames: the staged kernels).  Same rays, same image either way."""
+    monkeypatch.delenv("RT_TAIL_ADAPT", raising=False)
+    monkeypatch.setenv("RT_TAIL", "20000")  # small frames: let the tail take over while there is still a staged iteration before it
+    for scene in ("miku", "utah"):
+        hs = rt.HostScene(scene, 16 / 9)
+        ds = rt.DeviceScene(gpu_ctx, hs.desc)
+        p = rt.default_params(256, 144, 6, seed=11)
+        a0, s0 = ds.render(hs.camera, p)
+        for _ in range(2):
+            a, st = ds.render(hs.camera, p)
+            assert (st.rays_closest, st.rays_shadow, st.camera_samples) == (s0.rays_closest, s0.rays_shadow, s0.camera_samples)
+            assert_radiance_close(a, a0, rel=1e-5)
+        ds.close()

@@ -624,7 +624,7 @@ int32_t rt_scene_create_ex(rt_context *ctx, const rt_scene_desc *d, uint32_t fla
         const bool pair_leaves = env_u32_allow_zero("RT_BVH_DEV_PAIRS", 1) != 0;
         if (e == hipSuccess)
             e = build_bvh_device(ctx->stream, bvh_v, bvh_prim, bvh_mat, n_bvh, ordered, s->nodes.p, s->cnodes.p, s->tris.p, order.data(), qp, widen, pair_leaves,
-                                 &n_cnodes);
+                                 env_u32_allow_zero("RT_BVH_DEV_ROTATE", 1) != 0, &n_cnodes);
         for (int a = 0; a < 3; a++) { bvh.q_lo[a] = qp[a]; bvh.q_scale[a] = qp[3 + a]; }
         if (e != hipSuccess) return cleanup_fail(e, "BVH build on the device");
         // host copy of the triangle records, in the device's leaf order: the primitive -> record table below reads it

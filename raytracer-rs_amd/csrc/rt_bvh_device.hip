@@ -142,62 +142,116 @@ __global__ __launch_bounds__(BB) void k_bvh_hierarchy(const unsigned long long *
 #define NF_DEAD 4u      /* leaf under such a node: not emitted */
 #define NF_WIDE 8u      /* inner node that has taken a dissolved child's children: not dissolved itself (at most four children) */
 
-__device__ __forceinline__ float box_area(const volatile Box6 *b) {
-    const float dx = b->mx[0] - b->mn[0], dy = b->mx[1] - b->mn[1], dz = b->mx[2] - b->mn[2];
-    return 2.0f * (dx * dy + dy * dz + dz * dx);
-}
-
 // bottom-up: the second thread to arrive at an inner node owns it.  Release before the counter, acquire after it: the
-// children's boxes (and sizes) were written by other compute units.  Besides the box the owner decides how its children
-// appear in the thinned tree — a child node whose surface exceeds `widen` x the node's own is dissolved (the host
-// builder's rule for two children: a box test that fails less than half the time costs more than it saves), unless that
-// child has itself taken in a dissolved node's children (chains of dissolved nodes would make lists of dozens of boxes,
-// each tested by every ray that meets the first: measured 3x slower) — and counts the nodes of its thinned subtree,
-// itself included: sz.
-__global__ __launch_bounds__(BB) void k_bvh_refit(int n, const int2 *children, const int *parent, int *arrived, Box6 *nbox, int *sz, unsigned char *flags,
-                                                  float widen, int pair_leaves) {
+// children's boxes (and sizes) were written by other compute units.  The owner
+//  (1) may ROTATE the tree below the node (`rotate`): Morton splits know nothing of surfaces, and swapping a child with a
+//      grandchild on the other side — the four candidates of a tree rotation — changes one box only, that of the child
+//      whose children change; the swap that shrinks that box most is applied (the surface-area cost of the tree falls
+//      by the difference).  Both subtrees are complete when the owner arrives, so nothing else touches them;
+//  (2) decides how the node's children appear in the thinned tree — a child node whose surface exceeds `widen` x the
+//      node's own is dissolved (the host builder's rule for two children: a box test that fails less than half the time
+//      costs more than it saves), unless that child has itself taken in a dissolved node's children (chains of dissolved
+//      nodes would make lists of dozens of boxes, each tested by every ray that meets the first: measured 3x slower); two
+//      leaf children that are neighbours in sorted order become one leaf of two triangles;
+//  (3) counts the nodes of its thinned subtree, itself included: sz.
+__global__ __launch_bounds__(BB) void k_bvh_refit(int n, int2 *children, int *parent, int *arrived, Box6 *nbox, int *sz, unsigned char *flags, float widen,
+                                                  int pair_leaves, int rotate) {
     const int j = blockIdx.x * BB + threadIdx.x;
     if (j >= n) return;
+    auto load_children = [&](int i) {
+        const volatile int *cp = (const volatile int *)&children[i];
+        return make_int2(cp[0], cp[1]);
+    };
+    auto load_box = [&](int i) {
+        const volatile Box6 *b = &nbox[i];
+        Box6 r;
+        for (int k = 0; k < 3; k++) { r.mn[k] = b->mn[k]; r.mx[k] = b->mx[k]; }
+        return r;
+    };
+    auto unite = [](const Box6 &a, const Box6 &b) {
+        Box6 u;
+        for (int k = 0; k < 3; k++) { u.mn[k] = fminf(a.mn[k], b.mn[k]); u.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+        return u;
+    };
+    auto area_of = [](const Box6 &b) {
+        const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    };
+    // flags of x's children and x's own flags and size, from x's current children and box (steps 2 and 3)
+    auto finish_node = [&](int x, const Box6 &xbox) {
+        const volatile int *cp = (const volatile int *)&children[x];
+        const int ch[2] = {cp[0], cp[1]};
+        const bool leaf_a = ch[0] >= n - 1, leaf_b = ch[1] >= n - 1;
+        const bool pair = pair_leaves && leaf_a && leaf_b && (ch[0] - ch[1] == 1 || ch[1] - ch[0] == 1);
+        const unsigned char keep = (unsigned char)(((volatile unsigned char *)flags)[x] & NF_DISSOLVED); // decided by x's parent, later
+        if (pair) {
+            flags[x] = (unsigned char)(keep | NF_PAIR);
+            flags[ch[0]] = NF_DEAD;
+            flags[ch[1]] = NF_DEAD;
+            sz[x] = 1;
+            return;
+        }
+        const float area = area_of(xbox);
+        int total = 1;
+        unsigned wide = 0u;
+        for (int k = 0; k < 2; k++) {
+            if (ch[k] >= n - 1) { flags[ch[k]] = 0; total += 1; continue; }
+            const unsigned char f = (unsigned char)(((volatile unsigned char *)flags)[ch[k]] & ~NF_DISSOLVED);
+            const int s = ((volatile int *)sz)[ch[k]];
+            if (!(f & (NF_PAIR | NF_WIDE)) && widen > 0.0f && area_of(load_box(ch[k])) > widen * area) {
+                flags[ch[k]] = (unsigned char)(f | NF_DISSOLVED);
+                total += s - 1;
+                wide = NF_WIDE;
+            } else {
+                flags[ch[k]] = f;
+                total += s;
+            }
+        }
+        flags[x] = (unsigned char)(keep | wide);
+        sz[x] = total;
+    };
     int cur = parent[(n - 1) + j];
     while (cur >= 0) {
         __threadfence();
         if (atomicAdd(&arrived[cur], 1) == 0) return;
         __threadfence();
-        const int2 c = children[cur];
-        const volatile Box6 *a = &nbox[c.x], *b = &nbox[c.y];
-        Box6 u;
-        for (int k = 0; k < 3; k++) {
-            u.mn[k] = fminf(a->mn[k], b->mn[k]);
-            u.mx[k] = fmaxf(a->mx[k], b->mx[k]);
-        }
+        int2 c = load_children(cur);
+        const Box6 ba = load_box(c.x), bb = load_box(c.y);
+        const Box6 u = unite(ba, bb);
         nbox[cur] = u;
-        const bool leaf_a = c.x >= n - 1, leaf_b = c.y >= n - 1;
-        if (pair_leaves && leaf_a && leaf_b) {
-            flags[cur] = NF_PAIR;
-            flags[c.x] = NF_DEAD;
-            flags[c.y] = NF_DEAD;
-            sz[cur] = 1;
-        } else {
-            const float area = 2.0f * ((u.mx[0] - u.mn[0]) * (u.mx[1] - u.mn[1]) + (u.mx[1] - u.mn[1]) * (u.mx[2] - u.mn[2]) + (u.mx[2] - u.mn[2]) * (u.mx[0] - u.mn[0]));
-            int total = 1;
-            unsigned wide = 0u;
-            const int ch[2] = {c.x, c.y};
-            for (int k = 0; k < 2; k++) {
-                if (ch[k] >= n - 1) { total += 1; continue; }
-                const volatile unsigned char *fp = &flags[ch[k]];
-                const volatile int *sp = &sz[ch[k]];
-                const unsigned char f = *fp;
-                if (!(f & (NF_PAIR | NF_WIDE)) && widen > 0.0f && box_area(&nbox[ch[k]]) > widen * area) {
-                    flags[ch[k]] = (unsigned char)(f | NF_DISSOLVED);
-                    total += *sp - 1;
-                    wide = NF_WIDE;
-                } else {
-                    total += *sp;
-                }
+        if (rotate) {
+            // X = the child whose children change, Y = the other child of cur, which changes places with X's child `which`
+            float best = 0.0f;
+            int best_x = -1, best_which = 0;
+            for (int side = 0; side < 2; side++) {
+                const int X = side ? c.y : c.x;
+                if (X >= n - 1) continue; // a leaf has no children to trade
+                const Box6 &by = side ? ba : bb;
+                const int2 xc = load_children(X);
+                const float ax = area_of(side ? bb : ba);
+                const float d0 = area_of(unite(by, load_box(xc.y))) - ax; // Y takes the place of X's first child
+                const float d1 = area_of(unite(load_box(xc.x), by)) - ax; // ... of X's second child
+                if (d0 < best) { best = d0; best_x = X; best_which = 0; }
+                if (d1 < best) { best = d1; best_x = X; best_which = 1; }
             }
-            flags[cur] = (unsigned char)wide;
-            sz[cur] = total;
+            if (best_x >= 0 && best < -1e-6f * area_of(u)) {
+                const int X = best_x, Y = (X == c.x) ? c.y : c.x;
+                int2 xc = load_children(X);
+                const int up = best_which ? xc.y : xc.x; // goes up to cur
+                if (best_which) xc.y = Y; else xc.x = Y;
+                children[X] = xc;
+                if (X == c.x) c.y = up; else c.x = up;
+                children[cur] = c;
+                parent[Y] = X;
+                parent[up] = cur;
+                const Box6 xb = unite(load_box(xc.x), load_box(xc.y));
+                nbox[X] = xb;
+                __threadfence();
+                finish_node(X, xb);
+                __threadfence();
+            }
         }
+        finish_node(cur, u);
         cur = parent[cur];
     }
 }
@@ -240,7 +294,8 @@ __global__ __launch_bounds__(BB) void k_bvh_thread(int n, int n_orders, const in
         link = ~((idx - (n - 1)) * 8);
     }
     int miss = -1, cur = idx;
-    for (int p = parent[cur]; p >= 0; p = parent[cur]) {
+    int guard = nn; // (see k_bvh_compact)
+    for (int p = parent[cur]; p >= 0 && guard > 0; p = parent[cur], guard--) {
         const int2 c = children[p];
         const bool sw = (swap_mask[p] >> ko) & 1;
         const int first = sw ? c.y : c.x, second = sw ? c.x : c.y;
@@ -281,13 +336,15 @@ __global__ __launch_bounds__(BB) void k_bvh_compact(int n, int n_orders, const i
     // emitted nodes under and including c, as its parent's list sees it
     auto size_of = [&](int c) { return c >= n - 1 ? ((flags[c] & NF_DEAD) ? 0 : 1) : sz[c] - ((flags[c] & NF_DISSOLVED) ? 1 : 0); };
     int pos = 0, cur = idx;
-    for (int p = parent[cur]; p >= 0; p = parent[cur]) {
+    int guard = nn; // (a consistent tree is at most n deep: the bound only keeps a broken one from hanging the GPU)
+    for (int p = parent[cur]; p >= 0 && guard > 0; p = parent[cur], guard--) {
         const int2 c = children[p];
         const bool sw = (swap_mask[p] >> ko) & 1;
         const int first = sw ? c.y : c.x;
         pos += ((flags[p] & NF_DISSOLVED) ? 0 : 1) + (cur == first ? 0 : size_of(first));
         cur = p;
     }
+    if (pos >= stride) return; // (never in a consistent tree)
     const Box6 root = nbox[0], b = nbox[idx];
     uint32_t w[3];
     for (int a = 0; a < 3; a++) {
@@ -300,7 +357,7 @@ __global__ __launch_bounds__(BB) void k_bvh_compact(int n, int n_orders, const i
     }
     uint32_t last;
     if (idx >= n - 1) last = 0x80000000u | (uint32_t)((idx - (n - 1)) * 8);
-    else if (f & NF_PAIR) last = 0x80000000u | (uint32_t)(range[idx].x * 8 + 1); // two triangles, neighbours in sorted order
+    else if (f & NF_PAIR) last = 0x80000000u | (uint32_t)((min(children[idx].x, children[idx].y) - (n - 1)) * 8 + 1); // two triangles, neighbours in sorted order
     else last = (uint32_t)(pos + sz[idx]);
     cnodes[(size_t)k * (size_t)stride + (size_t)pos] = make_uint4(w[0], w[1], w[2], last);
 }
@@ -325,7 +382,7 @@ inline unsigned grid_for(long long n) { return (unsigned)((n + BB - 1) / BB); }
 
 hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const int32_t *prim_host, const int32_t *mat_host, int n, bool ordered,
                             float4 *nodes_dev, uint4 *cnodes_dev, float4 *tris_dev, uint32_t *order_host, float *q_params_host, float widen,
-                            bool pair_leaves, int *n_cnodes) {
+                            bool pair_leaves, bool rotate, int *n_cnodes) {
     if (n_cnodes) *n_cnodes = 0;
     if (n <= 0) return hipSuccess;
     const int nn = 2 * n - 1, n_orders = ordered ? 8 : 1;
@@ -377,7 +434,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float *tri_v_host, const i
     hipLaunchKernelGGL(k_bvh_emit_tris, dim3(grid_for(n)), dim3(BB), 0, stream, tri_v, prim, mat, keys_out, n, tbox, tris_dev, nbox);
     if (n > 1) {
         hipLaunchKernelGGL(k_bvh_hierarchy, dim3(grid_for(n - 1)), dim3(BB), 0, stream, keys_out, n, children, parent, range);
-        hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox, sz, flags, widen, pair_leaves ? 1 : 0);
+        hipLaunchKernelGGL(k_bvh_refit, dim3(grid_for(n)), dim3(BB), 0, stream, n, children, parent, arrived, nbox, sz, flags, widen, pair_leaves ? 1 : 0, rotate ? 1 : 0);
         hipLaunchKernelGGL(k_bvh_order, dim3(grid_for(n - 1)), dim3(BB), 0, stream, n, children, nbox, swap_mask);
     } else {
         const int minus_one = -1;

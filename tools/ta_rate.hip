@@ -97,6 +97,28 @@ __global__ __launch_bounds__(256) void k_loads(const uint4 *table, uint32_t n_sl
     if (acc == 0x12345u) sink[gid & 1023u] = acc; // keeps the loads alive
 }
 
+// Does it pay to keep every XCD (workgroup id mod 8: the dispatcher deals workgroups out to the eight dies in turn) to
+// an eighth of the table of its own?  Each die's L2 then holds 1/8 of the footprint.  Independent 16-byte loads.
+template <bool SLICED>
+__global__ __launch_bounds__(256) void k_sliced(const uint4 *table, uint32_t n_slots, uint32_t iters, uint32_t *sink) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(table), (short)0, (int)(n_slots * 16u), 0x00020000);
+    const uint32_t per = n_slots / 8u, base = SLICED ? (blockIdx.x % 8u) * per : 0u, span = SLICED ? per : n_slots;
+    uint32_t s = mix32(gid), acc = 0;
+    for (uint32_t i = 0; i < iters; i += 8) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            s = s * 1664525u + 1013904223u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((base + __umulhi(mix32(s), span)) * 16u), 0, 0);
+            w[k] = v.x ^ v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += w[k];
+    }
+    if (acc == 0x12345u) sink[gid & 1023u] = acc;
+}
+
 // One lane fetches a whole record by itself: PIECES loads of 16 bytes at consecutive addresses, records STRIDE bytes apart
 // (48: packed triangle records, which straddle cache lines; 32 / 64: aligned records).  Independent records, 2 per round.
 template <int PIECES, int STRIDE>
@@ -152,6 +174,29 @@ static Result run(const char *name, const uint4 *table, uint32_t n_slots, uint32
     const double waves = (double)blocks * 4.0;
     const double lanes_on = active >= 64u ? 64.0 : (double)active; // expected; the subset is pseudo-random
     Result r{name, WIDTH, (int)active, waves_per_simd, CHAIN, SAME_LINE, ms, waves * lanes_on * iters / (ms * 1e-3) / 1e9, waves * iters / (ms * 1e-3) / 1e9};
+    return r;
+}
+
+template <bool SLICED>
+static Result run_sliced(const char *name, const uint4 *table, uint32_t n_slots, uint32_t *sink, int n_cu) {
+    const uint32_t blocks = (uint32_t)(n_cu * 8), iters = 8192u;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float ms = 0.0f;
+    for (int rep = 0; rep < 4; rep++) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_sliced<SLICED>), dim3(blocks), dim3(256), 0, 0, table, n_slots, iters, sink);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float t;
+        CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (rep == 1 || (rep > 1 && t < ms)) ms = t;
+    }
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+    const double waves = (double)blocks * 4.0;
+    Result r{name, 16, 64, 8, false, false, ms, waves * 64.0 * iters / (ms * 1e-3) / 1e9, waves * iters / (ms * 1e-3) / 1e9};
     return r;
 }
 
@@ -237,6 +282,10 @@ int main(int argc, char **argv) {
     rs.push_back(run_records<3, 64>("records of 48 B in 64 B slots, one lane each (3 loads), independent", table, n_slots, 8, sink, n_cu));
     rs.push_back(run_records<4, 64>("records of 64 B, one lane each (4 loads), independent", table, n_slots, 8, sink, n_cu));
     rs.push_back(run_records<1, 16>("records of 16 B, one lane each (1 load), independent", table, n_slots, 8, sink, n_cu));
+
+    // one eighth of the table per XCD
+    rs.push_back(run_sliced<false>("divergent 16 B, independent, every workgroup over the whole table", table, n_slots, sink, n_cu));
+    rs.push_back(run_sliced<true>("divergent 16 B, independent, workgroup b over eighth (b mod 8) of the table", table, n_slots, sink, n_cu));
 
     if (json) {
         std::printf("{\"device\": \"%s\", \"compute_units\": %d, \"footprint_bytes\": %zu, \"peak_divergent_16B_Glane_per_s\": %.2f, \"rows\": [", prop.gcnArchName, n_cu,

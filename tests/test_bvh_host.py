@@ -194,6 +194,40 @@ def test_widening_dissolves_nodes_that_cannot_cull(rt, monkeypatch):
         assert (t, p) == want and visited <= wide.shape[1]
 
 
+@pytest.mark.parametrize("passes", ["0", "1", "8"])
+def test_tree_rotations_keep_every_hit(rt, monkeypatch, passes):
+    """The builder may swap subtrees after the top-down build (RT_BVH_ROTATE passes): every triangle stays in exactly
+    one leaf, and a walk finds what a scan of all triangles finds, in every visiting order."""
+    n = 500
+    tri_v = soup(n, 123, False)
+    monkeypatch.setenv("RT_BVH_ROTATE", passes)
+    nodes, tris, _ = rt.bvh_build_host(tri_v, max_top=8, ordered=True)
+    link = nodes[0, :, 6].view(np.int32)
+    leaves = link[link < 0]
+    covered = np.zeros(n, int)
+    for code in ~leaves:
+        first, count = int(code) >> 3, (int(code) & 7) + 1
+        covered[first:first + count] += 1
+    assert (covered == 1).all()
+    rng = np.random.default_rng(9)
+    for r in range(40):
+        o = rng.uniform(-14, 14, 3).astype(F)
+        d = (tri_v[rng.integers(n)].reshape(3, 3).mean(0) + rng.normal(0, 0.2, 3) - o).astype(F)
+        want = brute(tris, o, d, F(1e-3), F(1e7))
+        for k in (0, 5, 7):
+            t, p, _ = walk(nodes[k], tris, o, d, F(1e-3), F(1e7))
+            assert (t, p) == want, (r, k)
+
+
+def test_tree_rotations_change_the_tree(rt, monkeypatch):
+    tri_v = soup(2000, 5, False)
+    monkeypatch.setenv("RT_BVH_ROTATE", "0")
+    plain, _, _ = rt.bvh_build_host(tri_v, 8, False)
+    monkeypatch.setenv("RT_BVH_ROTATE", "8")
+    rotated, _, _ = rt.bvh_build_host(tri_v, 8, False)
+    assert plain.shape != rotated.shape or not np.array_equal(plain, rotated)
+
+
 def test_empty_and_argument_errors(rt):
     nodes, tris, n_top = rt.bvh_build_host(np.zeros((0, 9), F))
     assert nodes.shape[1] == 0 and tris.shape[0] == 0 and n_top == 0

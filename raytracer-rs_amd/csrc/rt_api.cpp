@@ -893,6 +893,11 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         const bool overlap = env_u32_allow_zero("RT_OVERLAP", 1) != 0;
         hipStream_t shadow_stream = overlap ? ctx->stream2 : ctx->stream;
         bool shadow_pending = false;
+        // The main stream's ray generation and extend kernels are submitted before the occlusion kernel of the second
+        // stream: they are the critical path (the occlusion kernel only has to be through before the next k_plan), and
+        // whichever kernel is submitted first gets the idle GPU.  Measured 1-3 % per frame on the Utah, Miku and composite
+        // frames against the other order (RT_SHADOW_LATE=0).
+        const bool shadow_late = overlap && env_u32_allow_zero("RT_SHADOW_LATE", 1) != 0;
         const bool dump_iter = std::getenv("RT_DUMP_ITER") != nullptr;
         // paths left when the staged iterations hand over to k_tail (RT_TAIL, 0 = never); not for the Whitted shader
         // (several shadow rays per node) nor for work-counting calls
@@ -938,7 +943,10 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c.n_alive, c.n_new, c.max_sh_light,
                              c.max_sh_heavy);
             // occlusion queries queued by the previous iteration's shading, now with exact per-class counts
-            if (c.max_sh_light || c.max_sh_heavy) {
+            bool shadow_launched = false;
+            auto launch_pending_shadow = [&]() -> int {
+                shadow_launched = true;
+                if (!(c.max_sh_light || c.max_sh_heavy)) return RT_OK;
                 ShadowQueue filled{pool.sa[scur ^ 1], pool.sb[scur ^ 1], pool.sc2[scur ^ 1]};
                 LaunchCfg scfg = cfg;
                 scfg.stream = shadow_stream;
@@ -949,6 +957,11 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
                 if (overlap) HIP_TRY(hipEventRecord(ctx->shadow_done, shadow_stream));
                 shadow_pending = true;
                 st.launches_shadow++;
+                return RT_OK;
+            };
+            if (!shadow_late || c.done) {
+                const int src = launch_pending_shadow();
+                if (src) return loop_fail(src, rt_last_error());
             }
             if (c.done) break;
             NodeQueue in{pool.qa[cur], pool.qb[cur], pool.qc[cur], pool.ql[cur]};
@@ -969,6 +982,10 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             const bool draining = c.n_new == 0 && c.cursor == c.total;
             if (draining) drain_iters++;
             if (tail_limit && tail_pays && draining && c.n_alive <= tail_limit) {
+                if (!shadow_launched) {
+                    const int src = launch_pending_shadow();
+                    if (src) return loop_fail(src, rt_last_error());
+                }
                 // the last few paths: one launch follows each of them to its end (see k_tail)
                 if (last_staged_ms >= 0.0 && tail_bounces_left == 0 && s->tail_ms_per_bounce[tail_key] < 0.0)
                     tail_bounces_left = std::max(1, p->max_depth + 1 - drain_iters); // (an upper bound: the youngest path left was born drain_iters ago)
@@ -992,6 +1009,10 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
             launch_extend(cfg, s->dev, rcst, pool.ctl, in, pool.hit, light_threads, heavy_threads, count_work);
             timer.end();
             st.launches_extend++;
+            if (!shadow_launched) {
+                const int src = launch_pending_shadow();
+                if (src) return loop_fail(src, rt_last_error());
+            }
             // Light occlusion queries answered by the shading kernel itself: measured -5 % per frame when few rays are heavy
             // (Utah teapot: 5 %), +1 to +2.5 % when none are (the occlusion kernel then overlaps with everything on the
             // second stream) or when many are (Miku, composite).  The choice only moves work: results are the same.

@@ -91,6 +91,7 @@ struct rt_context {
     Ctl *ctl = nullptr;          // device
     unsigned char *scratch_ptr = nullptr; // this device's copy of the fixed array behind rt_render_static
     CtlHead *ctl_host = nullptr; // pinned copy of the head
+    CtlHead *ctl_host_dev = nullptr; // the same memory as the device addresses it (k_plan writes the head there)
     std::vector<hipEvent_t> events;
 };
 
@@ -289,7 +290,12 @@ struct StageTimer {
         if (failed) { spans.clear(); used = 0; for (double &m : ms) m = 0.0; return; }
         for (const Span &s : spans) {
             float t = 0.0f;
-            if (hipEventElapsedTime(&t, ctx->events[s.e0], ctx->events[s.e0 + 1]) == hipSuccess) ms[s.stage] += t;
+            hipError_t e = hipEventElapsedTime(&t, ctx->events[s.e0], ctx->events[s.e0 + 1]);
+            if (e == hipErrorNotReady) { // (the host learns of the iteration's end from k_plan itself, perhaps before the runtime has looked at the events)
+                (void)hipEventSynchronize(ctx->events[s.e0 + 1]);
+                e = hipEventElapsedTime(&t, ctx->events[s.e0], ctx->events[s.e0 + 1]);
+            }
+            if (e == hipSuccess) ms[s.stage] += t;
         }
         spans.clear();
         used = 0;
@@ -357,7 +363,8 @@ int32_t rt_context_create(int32_t device_id, rt_context **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->shadow_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->ctl, sizeof(Ctl));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->ctl_host, sizeof(CtlHead), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&ctx->ctl_host_dev, ctx->ctl_host, 0);
     if (e == hipSuccess && device_id < RT_MAX_DEVICES) {
         // address of this device's copy of the fixed array (the device is current: hipSetDevice above).  A failed
         // lookup only takes rt_render_static away (it reports the missing array itself); rt_render does not need it.
@@ -893,6 +900,8 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         const bool overlap = env_u32_allow_zero("RT_OVERLAP", 1) != 0;
         hipStream_t shadow_stream = overlap ? ctx->stream2 : ctx->stream;
         bool shadow_pending = false;
+        const bool plan_poll = ctx->ctl_host_dev != nullptr && env_u32_allow_zero("RT_PLAN_POLL", 1) != 0; // 0: copy + stream synchronisation
+        uint32_t plan_seq = 0; // runs of k_plan so far (the head was uploaded with seq = 0)
         // The main stream's ray generation and extend kernels are submitted before the occlusion kernel of the second
         // stream: they are the critical path (the occlusion kernel only has to be through before the next k_plan), and
         // whichever kernel is submitted first gets the idle GPU.  Measured 1-3 % per frame on the Utah, Miku and composite
@@ -920,9 +929,26 @@ static int32_t render_in_pool(rt_scene *s, const rt_camera *cam, const rt_params
         for (;;) {
             if (shadow_pending && overlap) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->shadow_done, 0)); // k_plan rewrites the counts k_shadow reads
             shadow_pending = false;
-            launch_plan(cfg, pool.ctl);
-            HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &pool.ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (plan_poll) {
+                // k_plan writes the head into the pinned host copy itself, the sequence number last: no copy command, no
+                // wake-up through the runtime.  The stream is looked at now and then so that a failed launch ends the wait.
+                launch_plan(cfg, pool.ctl, ctx->ctl_host_dev);
+                plan_seq++;
+                for (uint64_t spins = 1;; spins++) {
+                    if (__atomic_load_n(&ctx->ctl_host->seq, __ATOMIC_ACQUIRE) == plan_seq) break;
+                    if ((spins & 0xFFFu) == 0u) {
+                        const hipError_t q = hipStreamQuery(ctx->stream);
+                        if (q == hipErrorNotReady) continue;
+                        if (q == hipSuccess && __atomic_load_n(&ctx->ctl_host->seq, __ATOMIC_ACQUIRE) == plan_seq) break;
+                        return loop_fail(RT_ERR_DEVICE, std::string("k_plan did not report: ") + hipGetErrorString(q == hipSuccess ? hipErrorUnknown : q));
+                    }
+                    __builtin_ia32_pause();
+                }
+            } else {
+                launch_plan(cfg, pool.ctl);
+                HIP_TRY(hipMemcpyAsync(ctx->ctl_host, &pool.ctl->h, sizeof(CtlHead), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+            }
             timer.collect();
             const CtlHead c = *ctx->ctl_host;
             if (c.overflow) return loop_fail(RT_ERR_NOMEM, overflow_msg);

@@ -59,6 +59,8 @@ struct CtlHead {
     uint32_t iterations;
     uint32_t done;      // nothing left to do
     uint32_t overflow;  // a queue segment ran out of room (the render call fails)
+    uint32_t seq;       // runs of k_plan in this render call; in the host's copy it is written last (see k_plan)
+    uint32_t pad0;
     unsigned long long cursor; // next camera candidate not yet generated
     unsigned long long total;  // all camera candidates of this render call
     unsigned long long rays_closest, rays_shadow, cam_samples, nodes, tris;
@@ -87,7 +89,9 @@ struct LaunchCfg {
     uint32_t target;              // refill level: camera rays are generated while fewer nodes than this are alive
 };
 
-void launch_plan(const LaunchCfg &cfg, Ctl *ctl);
+// `host_head` (may be null): pinned host memory the kernel copies the head into when it is through, the sequence number
+// last — the host can wait for that number instead of a copy and a stream synchronisation.
+void launch_plan(const LaunchCfg &cfg, Ctl *ctl, CtlHead *host_head = nullptr);
 // Consumer grids are one-dimensional: RT_NSEG_HALF * heavy_blocks workgroups for the heavy segments first (they run
 // longest), then RT_NSEG_HALF * light_blocks for the light ones; *_threads = most elements in any one segment of the class.
 void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,

@@ -13,6 +13,8 @@
 
 #include "rt_kernels.h"
 
+#include <cstddef>
+
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -149,25 +151,8 @@ __device__ __forceinline__ Node load_node(const NodeQueue &q, uint32_t i) {
 }
 
 // ---- k_plan ---------------------------------------------------------------------------------------------------------
-__global__ void k_plan(Ctl *ctl, uint32_t target) {
-    if (blockIdx.x != 0) return;
-    __shared__ uint32_t s_in[RT_NSEG], s_out[RT_NSEG], s_sh[RT_NSEG], s_inl[RT_NSEG_HALF];
-    const uint32_t t = threadIdx.x;
-    if (t < RT_NSEG_HALF) {
-        s_inl[t] = ctl->seg_inline[t].v;
-        ctl->seg_inline[t].v = 0;
-    }
-    if (t < RT_NSEG) {
-        s_in[t] = ctl->seg_in[t].v;
-        s_out[t] = ctl->seg_out[t].v;
-        s_sh[t] = ctl->seg_shadow[t].v;
-        ctl->seg_in[t].v = s_out[t]; // the queue filled by the last iteration becomes the current one
-        ctl->seg_out[t].v = 0;
-        ctl->seg_shadow_cur[t] = s_sh[t]; // k_shadow of the last iteration runs after this kernel, with exact counts
-        ctl->seg_shadow[t].v = 0;
-    }
-    __syncthreads();
-    if (t != 0) return;
+// the bookkeeping of k_plan, by one thread: closes the iteration that just ran and decides the next one's camera rays
+__device__ __forceinline__ void plan_head(Ctl *ctl, uint32_t target, const uint32_t *s_in, const uint32_t *s_out, const uint32_t *s_sh, const uint32_t *s_inl) {
     uint32_t prev_in = 0, alive = 0, prev_shadow = 0, max_in[2] = {0, 0}, max_sh[2] = {0, 0};
     for (int k = 0; k < RT_NSEG; k++) {
         const int cls = k / RT_NSEG_HALF;
@@ -207,6 +192,40 @@ __global__ void k_plan(Ctl *ctl, uint32_t target) {
     h.max_sh_heavy = max_sh[1];
     h.done = (alive == 0 && n_new == 0) ? 1u : 0u;
     if (!h.done) h.iterations++;
+    h.seq++;
+}
+
+__global__ void k_plan(Ctl *ctl, uint32_t target, CtlHead *host_head) {
+    if (blockIdx.x != 0) return;
+    __shared__ uint32_t s_in[RT_NSEG], s_out[RT_NSEG], s_sh[RT_NSEG], s_inl[RT_NSEG_HALF];
+    const uint32_t t = threadIdx.x;
+    if (t < RT_NSEG_HALF) {
+        s_inl[t] = ctl->seg_inline[t].v;
+        ctl->seg_inline[t].v = 0;
+    }
+    if (t < RT_NSEG) {
+        s_in[t] = ctl->seg_in[t].v;
+        s_out[t] = ctl->seg_out[t].v;
+        s_sh[t] = ctl->seg_shadow[t].v;
+        ctl->seg_in[t].v = s_out[t]; // the queue filled by the last iteration becomes the current one
+        ctl->seg_out[t].v = 0;
+        ctl->seg_shadow_cur[t] = s_sh[t]; // k_shadow of the last iteration runs after this kernel, with exact counts
+        ctl->seg_shadow[t].v = 0;
+    }
+    __syncthreads();
+    if (t == 0) plan_head(ctl, target, s_in, s_out, s_sh, s_inl);
+    if (!host_head) return;
+    // the host waits for seq in its pinned copy: everything else first (a word per thread: stores to host memory are slow
+    // one after the other), then a fence, then seq
+    __syncthreads();
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&ctl->h);
+    volatile uint32_t *dst = reinterpret_cast<volatile uint32_t *>(host_head);
+    const uint32_t seq_word = (uint32_t)(offsetof(CtlHead, seq) / sizeof(uint32_t));
+    for (uint32_t i = t; i < sizeof(CtlHead) / sizeof(uint32_t); i += blockDim.x)
+        if (i != seq_word) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&host_head->seq, ctl->h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- k_raygen -------------------------------------------------------------------------------------------------------
@@ -1151,7 +1170,7 @@ static inline size_t lds_bytes(const DevScene &sc, bool use_lds) {
     return need;
 }
 
-void launch_plan(const LaunchCfg &cfg, Ctl *ctl) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target); }
+void launch_plan(const LaunchCfg &cfg, Ctl *ctl, CtlHead *host_head) { hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, cfg.stream, ctl, cfg.target, host_head); }
 
 void launch_raygen(const LaunchCfg &cfg, const DevScene &sc, const RenderConst &rc, Ctl *ctl, NodeQueue in, const int32_t *blocks, uint32_t blocks_w,
                    uint32_t n_threads) {

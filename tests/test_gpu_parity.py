@@ -170,7 +170,7 @@ def test_small_queues_force_regeneration_and_give_the_same_image(rt, gpu_ctx, mo
 KNOBS = [{"RT_CARRY": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "2", "RT_TAIL": "0"}, {"RT_CARRY": "2", "RT_INLINE_SHADOW": "0"}, {"RT_CARRY": "1", "RT_INLINE_SHADOW": "1", "RT_QUEUE_TARGET": "30000"}, {"RT_DEFERRED": "0"}, {"RT_WALK_SPAN": "1"}, {"RT_WALK_SPAN": "16", "RT_QUEUE_TARGET": "100000"}, {"RT_INLINE_SHADOW": "0"}, {"RT_INLINE_SHADOW": "2"}, {"RT_INLINE_SHADOW": "2", "RT_LOOSE_MAX": "0"}, {"RT_BVH_ORDERED": "0"}, {"RT_BVH_ARITY": "2"}, {"RT_BVH_ARITY": "3", "RT_BVH_ORDERED": "0"}, {"RT_BVH_LEAF": "1"}, {"RT_BVH_LEAF": "4"}, {"RT_BVH_TOP": "0"}, {"RT_BVH_TOP": "300"}, {"RT_NO_HEAVY": "1"}, {"RT_LOOSE_MAX": "0"}, {"RT_LOOSE_MAX": "5"}, {"RT_TAIL": "0"}, {"RT_TAIL": "300"},
          {"RT_OVERLAP": "0"}, {"RT_BVH_ORDERED": "0", "RT_BVH_LEAF": "3", "RT_BVH_TOP": "7", "RT_OVERLAP": "0", "RT_QUEUE_TARGET": "40000"},
          {"RT_LOOSE_BOXES": "0"}, {"RT_LOOSE_BOXES": "0", "RT_INLINE_SHADOW": "0", "RT_CARRY": "0"}, {"RT_TAIL_ADAPT": "0"}, {"RT_BVH_ROTATE": "0"}, {"RT_BVH_ROTATE": "1", "RT_BVH_ARITY": "2"},
-         {"RT_SHADOW_LATE": "0"}, {"RT_SHADOW_LATE": "0", "RT_TAIL": "300", "RT_QUEUE_TARGET": "30000"}]
+         {"RT_SHADOW_LATE": "0"}, {"RT_SHADOW_LATE": "0", "RT_TAIL": "300", "RT_QUEUE_TARGET": "30000"}, {"RT_PLAN_POLL": "0"}, {"RT_PLAN_POLL": "0", "RT_OVERLAP": "0"}]
 
 
 @pytest.mark.parametrize("env", KNOBS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
